@@ -1,0 +1,151 @@
+/*
+ * vortex_hip.h — C ABI of libvortex_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for Vortex's detection pre/post-process path.  Plain
+ * pointers and sizes only; every pointer named `d_*` is DEVICE memory, every
+ * other pointer is HOST memory read before the call returns.  `stream` is a
+ * hipStream_t passed as void*.  No entry point allocates, frees or synchronises:
+ * the caller owns outputs and workspace (sizes from the *_workspace_bytes
+ * queries) and reads counts / status words back itself.
+ *
+ * All reference citations are relative to
+ *   /root/reference/src/development/vortex/development/   (unless they start with src/runtime)
+ *
+ * Return value: VX_OK or a negative VX_ERR_* code (argument / limit checks are
+ * done on the host before any launch).  Data-dependent conditions that the
+ * reference raises on (NaN in predictions) are reported through the device
+ * `d_status` word, see VX_STATUS_*.
+ */
+#ifndef VORTEX_HIP_H
+#define VORTEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK                 0
+#define VX_ERR_INVALID_ARG   (-1)   /* null pointer, non-positive dimension, bad enum   */
+#define VX_ERR_UNSUPPORTED   (-2)   /* a documented limit exceeded (see each function)  */
+#define VX_ERR_WORKSPACE     (-3)   /* workspace smaller than *_workspace_bytes()       */
+#define VX_ERR_LAUNCH        (-4)   /* hipGetLastError() != hipSuccess after a launch    */
+#define VX_ERR_ALIGNMENT     (-5)   /* a device pointer is not aligned as documented     */
+
+/* bits of the device status word (int32, caller zeroes it, kernels OR into it) */
+#define VX_STATUS_NAN         1     /* predictions contain NaN: postprocess/yolov3.py:35-36 -> ValueError */
+#define VX_STATUS_BAD_CLASS   2     /* class index outside [0, VX_MAX_CLASSES)           */
+
+#define VX_MAX_CLASSES        4096  /* sort key holds the class in 12 bits               */
+#define VX_MAX_CANDIDATES     1048575 /* per image; sort key holds the index in 20 bits  */
+#define VX_MAX_COORDINATE     2048  /* postprocess/utils/nms.py:94 */
+
+#define VX_RESIZE_STRETCH     0     /* src/runtime/vortex/runtime/basic_runtime.py:66-68 */
+#define VX_RESIZE_LETTERBOX   1     /* build-side extension (basic_runtime.py:70-73 is a TODO) */
+
+int         vx_version(void);
+const char *vx_error_string(int code);
+
+/* ---------------------------------------------------------------- K1 pre-process
+ * Replaces Normalize.forward / FlipNormalize.forward
+ *   (networks/modules/preprocess/normalizer.py:74-77, :91-95; to_tensor :13-31,
+ *    normalize :34-60, flip :5-11)
+ * and, when (Hs,Ws) != (Hd,Wd), BaseRuntime.resize_stretch in front of it
+ *   (src/runtime/vortex/runtime/basic_runtime.py:66-68, :75-90).
+ * d_src u8[B,Hs,Ws,3] (NHWC) -> d_dst f32[B,3,Hd,Wd] (NCHW, contiguous):
+ *   dst[b,c,y,x] = ((float(px) / scaler) - mean[c]) / std[c], px = src[b,y,x, flip ? 2-c : c]
+ * bit-exact with the reference for same-size input.  Resize: u8 bilinear, half-pixel
+ * centres, 11-bit fixed-point weights (OpenCV INTER_LINEAR scheme; parity unpinned).
+ * d_dst must be 16-byte aligned, d_src 4-byte aligned. */
+int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst,
+                                int B, int Hs, int Ws, int Hd, int Wd,
+                                const float mean[3], const float std[3], int scaler,
+                                int flip, int resize_mode, int pad_value, void *stream);
+
+/* ---------------------------------------------------------------- K2 YOLOv3 grid/anchor decode
+ * Replaces YoloV3Layer.forward, eval branch (networks/modules/heads/detection/yolov3.py:263-304;
+ * buffers :202-247) for ONE scale, writing straight into its slice of the concatenated
+ * tensor of YoloV3.forward (networks/models/detection/yolov3.py:72-76).
+ * d_in f32[B, 3*(5+C), G, G]  ->  d_out rows [row_offset, row_offset + 3*G*G) of f32[B, R_total, 5+C]
+ *   anchor_wh[a] = anchors[mask[a]] / stride (grid units, as the reference's anchor_wh buffer)
+ * Transcendentals are tolerance-class (1e-5 relative). Limit: 5+C <= 255. d_out 16-byte aligned. */
+int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G, int C,
+                        const float anchor_wh[6], float stride,
+                        int64_t out_batch_stride /* floats between images in d_out */,
+                        int64_t row_offset, void *stream);
+
+/* ---------------------------------------------------------------- K3 YOLOv3 decoder
+ * Replaces YoloV3Decoder.forward (networks/modules/postprocess/yolov3.py:29-68, yolo2xywh :9-17)
+ * for all B images in one call (the reference loops per image, base_postprocess.py:131-138).
+ * d_pred f32[B,R,5+C] (16-byte aligned).  Per image i, K_i rows with obj > score_threshold
+ * (all rows if use_threshold == 0), ascending row order:
+ *   d_boxes f32[B,R,4] xyxy/img_size, d_scores f32[B,R] = obj*class_conf,
+ *   d_cls i64[B,R] (first max wins), d_det f32[B,R,6] = box|class_conf|float(cls),
+ *   d_counts i32[B] = K_i.  Rows beyond K_i are left untouched.
+ * NaN anywhere in d_pred sets VX_STATUS_NAN in *d_status.  Bit-exact (no transcendentals). */
+size_t vx_yolo_decode_workspace_bytes(int B, int R);
+int vx_yolo_decode(const float *d_pred, int B, int R, int C, float img_size,
+                   float score_threshold, int use_threshold,
+                   float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                   int32_t *d_counts, int32_t *d_status,
+                   void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- K2+K3 fused
+ * YoloV3Layer (3 scales) + concat + YoloV3Decoder without materialising f32[B,R,5+C].
+ * d_heads[s] f32[B,3*(5+C),G_s,G_s] for G_s = S/32, S/16, S/8 (coarse -> fine, the h1,h2,h3
+ * order of heads/detection/yolov3.py:369-376); anchors_px[9][2] = the 9 anchors in pixels
+ * (models/detection/yolov3.py:26-29), masks (6,7,8),(3,4,5),(0,1,2) applied inside.
+ * Outputs as vx_yolo_decode with R = 3*sum(G_s^2).  Results are bit-identical to
+ * vx_yolo_head_decode x3 followed by vx_yolo_decode. */
+size_t vx_yolo_fused_workspace_bytes(int B, int S);
+int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, const float *d_head2,
+                         int B, int S, int C, const float anchors_px[18],
+                         float score_threshold, int use_threshold,
+                         float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                         int32_t *d_counts, int32_t *d_status,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- K4 prior-box decode (+landmarks)
+ * FPN-SSD / RetinaFace decoder.  The reference's source for it is absent from the snapshot
+ * (evidence: scripts/export_check/README.md:54-63,:107,:113); build-authored spec, see
+ * oracle/vortex_oracle.py:prior_box_decode.  d_in f32[B,P,4+2L+NC] = loc|landmarks|logits
+ * (logit 0 = background), d_priors f32[P,4] normalised cx,cy,w,h.
+ * Outputs as vx_yolo_decode with row width D = 6+2L: d_det f32[B,P,D]. */
+size_t vx_prior_decode_workspace_bytes(int B, int P, int n_landmarks);
+int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
+                    int n_landmarks, int n_logits, float variance0, float variance1,
+                    float score_threshold, int use_threshold,
+                    float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                    int32_t *d_counts, int32_t *d_status,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- K5-K7 class-aware batched NMS
+ * Replaces batched_nms + BatchedNMS.forward (networks/modules/postprocess/utils/nms.py:57-98,
+ * :105-123) and the per-image loop of BatchedNMSPostProcess.forward (base_postprocess.py:131-138).
+ * Per image i the first n_i = d_counts[i] (or `capacity` when d_counts == NULL) entries of
+ *   d_boxes f32[B,capacity,4], d_scores f32[B,capacity], d_cls i64[B,capacity], d_det f32[B,capacity,D]
+ * are candidates.  Greedy NMS in descending score order (ties: ascending index) on
+ * fl32(box + fl32(2049*cls)) exactly as the reference's offset trick; suppress when
+ * inter/(area_i+area_j-inter) > iou_threshold.  Outputs, per image:
+ *   d_keep_idx i64[B,out_capacity]   indices into the candidate list, score-descending
+ *   d_out_det  f32[B,out_capacity,D] = d_det rows gathered by keep (index_select, nms.py:122)
+ *   d_keep_counts i32[B]
+ * top_k > 0 truncates each keep list to its first top_k entries (build-side extension);
+ * out_capacity >= min(capacity, top_k>0 ? top_k : capacity).
+ * Limits: capacity <= VX_MAX_CANDIDATES, 0 <= cls < VX_MAX_CLASSES (else VX_STATUS_BAD_CLASS),
+ * |coordinate| < 1024 so that classes cannot overlap after the offset (always true for
+ * normalised boxes), iou_threshold >= 0. */
+size_t vx_batched_nms_workspace_bytes(int B, int capacity);
+int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
+                   const float *d_det, const int32_t *d_counts,
+                   int B, int capacity, int D, int n_classes /* <=0: VX_MAX_CLASSES */,
+                   float iou_threshold, int top_k,
+                   int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
+                   int out_capacity, int32_t *d_status,
+                   void *d_workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORTEX_HIP_H */

@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the nn.Module mirror of the reference API)
+against the committed golden vectors and the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for normalize, the YOLO decoder, NMS keep indices / counts and everything gathered
+from them; 1e-5 relative (+1e-6 absolute for values near 0) for the sigmoid/exp head decode and
+the softmax/exp prior-box decode (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import vortex_amd as V
+from vortex_amd import ops
+from oracle import vortex_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(a, b):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    ok = err <= ATOL + RTOL * b.abs()
+    assert bool(ok.all()), "max abs err %g, max rel err %g" % (float(err.max()), float((err / b.abs().clamp_min(1e-30)).max()))
+
+
+def same(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert a.tobytes() == b.tobytes() or np.array_equal(a, b), "not bit-exact: %d differing" % int((a != b).sum())
+
+
+# ------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("cfg", ["imagenet", "half", "unit"])
+def test_normalize_golden_bit_exact(golden, cfg):
+    g = golden("normalize")
+    mean, std = g["mean_" + cfg].tolist(), g["std_" + cfg].tolist()
+    n, f = V.Normalize(mean, std).to(DEV), V.FlipNormalize(mean, std).to(DEV)
+    for which in ("img", "sweep"):
+        x = T(g[which])
+        y = n(x)
+        assert y.is_contiguous() and y.dtype == torch.float32
+        same(y, g[f"norm_{which}_{cfg}"])
+        same(f(x), g[f"flip_{which}_{cfg}"])
+
+
+@pytest.mark.parametrize("shape", [(3, 416, 416), (2, 37, 53), (1, 64, 64), (5, 7, 9)])
+def test_normalize_vs_oracle_shapes(shape):
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    same(V.Normalize(mean, std).to(DEV)(img.to(DEV)), O.normalize(img, mean, std))
+    same(V.FlipNormalize(mean, std).to(DEV)(img.to(DEV)), O.normalize(img, mean, std, flip=True))
+    same(V.get_preprocess("normalizer", mean=[0.5] * 3, std=[0.5] * 3)(img.to(DEV)), O.normalize(img, [0.5] * 3, [0.5] * 3))
+
+
+@pytest.mark.parametrize("letterbox", [False, True])
+@pytest.mark.parametrize("src,dst", [((72, 128), (64, 64)), ((33, 21), (48, 40)), ((50, 50), (20, 30))])
+def test_resize_normalize_vs_oracle(src, dst, letterbox):
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (2, src[0], src[1], 3), dtype=np.uint8)
+    mean, std = [0.5, 0.4, 0.3], [0.2, 0.25, 0.3]
+    y = ops.preprocess(T(imgs), mean, std, 255, out_size=dst, letterbox=letterbox)
+    ref = np.stack([O.resize_bilinear_u8(im, dst[0], dst[1], letterbox) for im in imgs])
+    same(y, O.normalize(torch.from_numpy(ref), mean, std))
+
+
+# ------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("name,grid,C", [("g13_c80", 13, 80), ("g13_c1", 13, 1), ("g26_c3", 26, 3), ("g52_c2", 52, 2)])
+def test_yolo_layer_golden(golden, name, grid, C):
+    g = golden("yolo_layer")
+    layer = V.YoloV3Layer(img_size=416, grids=(grid, grid), mask=g["mask_" + name].tolist(),
+                          anchors=O.COCO_ANCHORS, n_classes=C).to(DEV).eval()
+    same(layer.anchor_wh.reshape(3, 2), g["anchor_wh_" + name])
+    y = layer(T(g["in_" + name]))
+    assert y.shape == g["out_" + name].shape
+    close(y, g["out_" + name])
+
+
+def test_yolo_layer_reference_test_pins():
+    """The reference's own head test (tests/models/test_yolo_head.py:82-156) run on the HIP layer."""
+    for C in (1, 80):
+        layer = V.YoloV3Layer(img_size=416, grids=V.yolo_feature_maps(416)[-1], mask=[6, 7, 8],
+                              anchors=O.COCO_ANCHORS, n_classes=C).to(DEV).eval()
+        x = layer(torch.rand([1, 3 * (5 + C), 13, 13]).to(DEV)).cpu()
+        meshgrid = torch.meshgrid([torch.arange(13), torch.arange(13)], indexing="ij")
+        meshgrid = torch.stack(tuple(reversed(meshgrid)), 2).view(1, 13 * 13, 2)
+        meshgrid = torch.cat((meshgrid.clone(), meshgrid.clone(), meshgrid.clone()), 1)
+        assert x.size() == torch.Size([1, 3 * 13 * 13, 5 + C])
+        assert torch.all(x[:, :, 4] >= 0) and torch.all(x[:, :, 4] <= 1)
+        assert torch.all(x[:, :, 5:] >= 0) and torch.all(x[:, :, 5:] <= 1)
+        assert torch.all(x[:, :, :2] >= meshgrid * 32) and torch.all(x[:, :, :2] <= (meshgrid + 1) * 32)
+
+
+def test_yolo_head_concat_416_and_extremes():
+    """Three scales written straight into the concatenated [B,10647,85] tensor; extreme logits."""
+    S, C, B = 416, 80, 2
+    heads = O.synth_yolo_heads(B, S, C, seed=3)
+    heads[0][0, 4, 0, 0] = 60.0
+    heads[0][0, 5, 0, 1] = -60.0
+    heads[1][1, 2, 3, 3] = 8.0
+    heads[2][0, 0, 5, 5] = -30.0
+    ref = O.yolo_head_eval(heads, S)
+    out = torch.empty((B, ops.yolo_rows(S), 5 + C), device=DEV)
+    off = 0
+    for h, mask in zip(heads, O.ANCHOR_MASKS):
+        G = h.shape[-1]
+        layer = V.YoloV3Layer(S, (G, G), list(mask), O.COCO_ANCHORS, C).to(DEV).eval()
+        layer(h.to(DEV), out=out, row_offset=off)
+        off += 3 * G * G
+    assert off == 10647
+    close(out, ref)
+
+
+# ------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("tname,thr", [("t50", 0.5), ("t06", 0.06), ("t00", 0.0), ("t90", 0.9)])
+def test_yolo_decoder_golden_bit_exact(golden, tname, thr):
+    g = golden("yolo_postprocess")
+    pred, S = T(g["pred"]), int(g["img_size"])
+    dec = V.YoloV3Decoder(img_size=S, threshold=True)
+    for b in range(pred.shape[0]):
+        bb, sc, ci, det = dec(pred[b:b + 1], torch.tensor([thr]))
+        k = f"dec_{tname}_b{b}_"
+        same(bb, g[k + "bboxes"]); same(sc, g[k + "scores"]); same(det, g[k + "det"])
+        assert ci.dtype == torch.int64
+        same(ci, g[k + "cls"])
+
+
+def test_yolo_decoder_nothreshold_nan_empty(golden):
+    g = golden("yolo_postprocess")
+    pred, S = T(g["pred"]), int(g["img_size"])
+    bb, sc, ci, det = V.YoloV3Decoder(S, threshold=False)(pred[0:1], torch.tensor([0.5]))
+    same(det, g["dec_nothr_b0_det"]); same(sc, g["dec_nothr_b0_scores"]); same(bb, g["dec_nothr_b0_bboxes"])
+    bb, sc, ci, det = V.YoloV3Decoder(S)(pred[0:1], torch.tensor([2.0]))
+    assert bb.shape == (0, 4) and sc.shape == (0,) and ci.shape == (0,) and det.shape == (1, 0, 6)
+    bad = pred[0:1].clone()
+    bad[0, 200, 33] = float("nan")
+    with pytest.raises(ValueError):
+        V.YoloV3Decoder(S)(bad, torch.tensor([0.5]))
+    with pytest.raises(ValueError):
+        V.YoloV3PostProcess(S)(bad, torch.tensor([0.5]), torch.tensor([0.5]))
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.06, 0.9])
+def test_yolo_decoder_416_vs_oracle(thr):
+    S, C, B = 416, 80, 3
+    pred = O.yolo_head_eval(O.synth_yolo_heads(B, S, C, seed=21), S)
+    c = ops.yolo_decode(pred.to(DEV), S, thr)
+    counts = c.counts.cpu().tolist()
+    for b in range(B):
+        bb, sc, ci, det = O.yolo_decoder(pred[b:b + 1], torch.tensor([thr]), S)
+        k = counts[b]
+        assert k == bb.shape[0]
+        same(c.boxes[b, :k], bb); same(c.scores[b, :k], sc); same(c.cls[b, :k], ci); same(c.det[b, :k], det[0])
+
+
+# ------------------------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize("name", ["k300_c80", "k500_c3", "k64_c1", "k1_c1"])
+def test_batched_nms_golden(golden, name):
+    g = golden("batched_nms")
+    boxes, scores, cls = T(g["boxes_" + name]), T(g["scores_" + name]), T(g["cls_" + name])
+    thr = torch.tensor(g["thr_" + name])
+    keep = V.batched_nms(boxes, scores, cls, thr)
+    assert keep.dtype == torch.int64
+    same(keep, g["keep_" + name])
+    res = V.BatchedNMS()(detections=T(g["det_" + name]), class_indexes=cls, bboxes=boxes, scores=scores, iou_threshold=thr)
+    same(res, g["res_" + name])
+
+
+def test_batched_nms_empty_and_ties():
+    k = V.batched_nms(torch.zeros(0, 4, device=DEV), torch.zeros(0, device=DEV),
+                      torch.zeros(0, dtype=torch.int64, device=DEV), torch.tensor([0.5]))
+    assert k.shape == (0,) and k.dtype == torch.int64
+    r = V.BatchedNMS()(detections=torch.zeros(1, 0, 6, device=DEV), class_indexes=torch.zeros(0, dtype=torch.int64, device=DEV),
+                       bboxes=torch.zeros(0, 4, device=DEV), scores=torch.zeros(0, device=DEV), iou_threshold=torch.tensor([0.5]))
+    assert r.shape == (1, 0, 6)
+    # equal scores: ties resolve to the lower index (stable), identical boxes suppress each other
+    boxes = torch.tensor([[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3], [0, 0, 1, 1]], dtype=torch.float32)
+    scores = torch.tensor([0.5, 0.5, 0.5, 0.7, 0.5])
+    cls = torch.tensor([0, 0, 1, 1, 1])
+    ref = O.batched_nms(boxes, scores, cls, torch.tensor([0.5]))
+    same(V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([0.5])), ref)
+    assert ref.tolist() == [3, 0, 4]
+
+
+@pytest.mark.parametrize("K,C,thr,seed", [(2000, 80, 0.45, 0), (2000, 80, 0.0, 1), (2000, 80, 1.0, 2),
+                                          (5000, 1, 0.3, 3), (3000, 2, 0.6, 4), (777, 4095, 0.5, 5),
+                                          (20000, 80, 0.45, 6), (40000, 3, 0.5, 7)])
+def test_batched_nms_vs_oracle(K, C, thr, seed):
+    """Wave path (small segments), block path (one big class), global-merge sort (K > 16384) and the
+    fp32 offset quantisation (dense overlapping boxes, classes up to 4095)."""
+    boxes, scores, cls = O.synth_stress_boxes(K, C, seed)
+    if seed % 2 == 0:
+        boxes = (boxes * 0.25 + 0.3).contiguous()
+    ref = O.batched_nms(boxes, scores, cls, torch.tensor([thr]))
+    keep = V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([thr]))
+    same(keep, ref)
+    det = torch.cat((boxes, scores[:, None], cls[:, None].float()), 1)[None]
+    same(V.BatchedNMS(top_k=100)(detections=det.to(DEV), class_indexes=cls.to(DEV), bboxes=boxes.to(DEV),
+                                  scores=scores.to(DEV), iou_threshold=torch.tensor([thr])), det[:, ref[:100]])
+
+
+def test_nms_class_agnostic_module():
+    boxes, scores, _ = O.synth_stress_boxes(1500, 1, 9)
+    det = torch.randn(1, 1500, 6)
+    ref = O.nms(boxes, scores, 0.4)
+    same(V.NMS()(detections=det.to(DEV), bboxes=boxes.to(DEV), scores=scores.to(DEV), iou_threshold=torch.tensor([0.4])), det[:, ref])
+
+
+# ------------------------------------------------------------------------------------------- post-process
+@pytest.mark.parametrize("pname", ["p06_20", "p00_100", "p90_20", "p001_45", "p00_00"])
+def test_postprocess_golden_bit_exact(golden, pname):
+    g = golden("yolo_postprocess")
+    pred, S = T(g["pred"]), int(g["img_size"])
+    sthr, ithr = g[f"post_{pname}_thr"]
+    res = V.YoloV3PostProcess(img_size=S)(pred, torch.tensor([sthr]), torch.tensor([ithr]))
+    assert isinstance(res, tuple) and len(res) == pred.shape[0]
+    for b, r in enumerate(res):
+        same(r, g[f"post_{pname}_b{b}"])
+
+
+@pytest.mark.parametrize("sthr,ithr", [(0.06, 0.2), (0.9, 0.2), (0.0, 1.0), (0.5, 0.45)])
+def test_postprocess_416_vs_oracle(sthr, ithr):
+    """BASELINE configs[0] shape (YOLOv3-416, 80 classes) at the shipped / dense / export-check thresholds."""
+    S, C, B = 416, 80, 4
+    pred = O.yolo_head_eval(O.synth_yolo_heads(B, S, C, seed=31), S)
+    ref = O.yolo_postprocess(pred, torch.tensor([sthr]), torch.tensor([ithr]), S)
+    res = V.YoloV3PostProcess(img_size=S)(pred.to(DEV), torch.tensor([sthr]), torch.tensor([ithr]))
+    for r, e in zip(res, ref):
+        same(r, e)
+    ref_k = O.yolo_postprocess(pred, torch.tensor([sthr]), torch.tensor([ithr]), S, top_k=25)
+    res_k = V.YoloV3PostProcess(img_size=S, top_k=25)(pred.to(DEV), torch.tensor([sthr]), torch.tensor([ithr]))
+    for r, e in zip(res_k, ref_k):
+        same(r, e)
+
+
+@pytest.mark.parametrize("sthr,ithr", [(0.06, 0.2), (0.9, 0.2), (0.5, 0.45)])
+def test_fused_equals_unfused_and_oracle(sthr, ithr):
+    """Fused raw-head path == YoloV3Layer x3 -> YoloV3PostProcess on the GPU bit for bit; against the
+    oracle: same surviving rows, boxes within 1e-5, and keep sets bit-exact given the GPU's candidates."""
+    S, C, B = 416, 80, 3
+    heads = O.synth_yolo_heads(B, S, C, seed=41)
+    dheads = [h.to(DEV) for h in heads]
+    fused = V.YoloV3FusedPostProcess(img_size=S)(dheads, torch.tensor([sthr]), torch.tensor([ithr]))
+    out = torch.empty((B, ops.yolo_rows(S), 5 + C), device=DEV)
+    off = 0
+    for h, mask in zip(dheads, O.ANCHOR_MASKS):
+        G = h.shape[-1]
+        V.YoloV3Layer(S, (G, G), list(mask), O.COCO_ANCHORS, C).to(DEV).eval()(h, out=out, row_offset=off)
+        off += 3 * G * G
+    unfused = V.YoloV3PostProcess(img_size=S)(out, torch.tensor([sthr]), torch.tensor([ithr]))
+    for f, u in zip(fused, unfused):
+        same(f, u)
+    # candidates vs oracle
+    pred = O.yolo_head_eval(heads, S)
+    assert float((pred[..., 4] - sthr).abs().min()) > 1e-6     # no borderline objectness in this seed
+    c = ops.yolo_fused_decode(dheads, S, sthr)
+    counts = c.counts.cpu().tolist()
+    for b in range(B):
+        bb, sc, ci, det = O.yolo_decoder(pred[b:b + 1], torch.tensor([sthr]), S)
+        k = counts[b]
+        assert k == bb.shape[0]
+        close(c.boxes[b, :k], bb); close(c.scores[b, :k], sc); close(c.det[b, :k, :5], det[0, :, :5])
+        same(c.cls[b, :k], ci)
+        # NMS from identical inputs: bit-exact keep
+        gb, gs, gc = c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu()
+        keep = O.batched_nms(gb, gs, gc, torch.tensor([ithr]))
+        same(fused[b], c.det[b, :k].cpu()[keep])
+
+
+# ------------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("L,NL,P,B,sthr", [(5, 2, 50400, 2, 0.5), (0, 21, 50400, 2, 0.3), (0, 21, 1000, 3, 0.0), (5, 2, 777, 1, 0.02)])
+def test_prior_decode_and_postprocess(L, NL, P, B, sthr):
+    priors = O.make_priors(640) if P == 50400 else torch.rand(P, 4) * 0.5 + 0.1
+    x = O.synth_prior_head(B, P, L, NL, seed=51)
+    c = ops.prior_decode(x.to(DEV), priors.to(DEV), L, sthr)
+    counts = c.counts.cpu().tolist()
+    pp = V.PriorBoxPostProcess(priors, n_landmarks=L).to(DEV)
+    res = pp(x.to(DEV), torch.tensor([sthr]), torch.tensor([0.4]))
+    for b in range(B):
+        bb, sc, ci, det = O.prior_box_decode(x[b:b + 1], priors, torch.tensor([sthr]), L)
+        k = counts[b]
+        assert k == bb.shape[0]
+        close(c.boxes[b, :k], bb); close(c.scores[b, :k], sc); same(c.cls[b, :k], ci)
+        cols = [0, 1, 2, 3, 4] + list(range(6, 6 + 2 * L))
+        close(c.det[b, :k][:, cols], det[0][:, cols]); same(c.det[b, :k, 5], det[0, :, 5])
+        gb, gs, gc = c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu()
+        keep = O.batched_nms(gb, gs, gc, torch.tensor([0.4]))
+        same(res[b], c.det[b, :k].cpu()[keep])
+        assert res[b].shape[1] == 6 + 2 * L
+
+
+# ------------------------------------------------------------------------------------------- callers
+def test_predictor_end_to_end_and_results():
+    """BasePredictor(preprocess -> model -> postprocess) with a stand-in model that returns a decoded head,
+    then get_prediction_results (predictor/utils.py:11-33)."""
+    S, C, B = 64, 80, 2
+    pred = O.yolo_head_eval(O.synth_yolo_heads(B, S, C, seed=7), S)
+
+    class Model(torch.nn.Module):
+        task = "detection"
+        output_format = {"bounding_box": {"indices": [0, 1, 2, 3], "axis": 1},
+                         "class_confidence": {"indices": [4], "axis": 1},
+                         "class_label": {"indices": [5], "axis": 1}}
+
+        def forward(self, x):
+            assert x.shape == (B, 3, S, S) and x.dtype == torch.float32
+            return pred.to(x.device)
+
+    p = V.create_predictor(dict(network=Model(), preprocess=V.Normalize(), postprocess=V.YoloV3PostProcess(S))).to(DEV)
+    img = O.synth_images(B, S).to(DEV)
+    res = p(img, score_threshold=torch.tensor([0.06]), iou_threshold=torch.tensor([0.2]))
+    ref = O.yolo_postprocess(pred, torch.tensor([0.06]), torch.tensor([0.2]), S)
+    for r, e in zip(res, ref):
+        same(r, e)
+    got = V.get_prediction_results(res, Model.output_format)
+    exp = O.get_prediction_results(ref, Model.output_format)
+    for a, b in zip(got, exp):
+        for k in b:
+            assert (a[k] is None and b[k] is None) or np.array_equal(a[k], b[k])

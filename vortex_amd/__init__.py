@@ -1,0 +1,24 @@
+"""vortex_amd — MI355X-native detection pre/post-process path of nodefluxio/vortex.
+
+Hand-written HIP kernels (vortex_amd/csrc, C ABI in include/vortex_hip.h) behind the
+reference's own nn.Module API for that path:
+
+    preprocess.Normalize / FlipNormalize / get_preprocess
+    heads.YoloV3Layer
+    postprocess.YoloV3Decoder / BatchedNMS / NMS / NoNMS / BatchedNMSPostProcess /
+                YoloV3PostProcess / YoloV3FusedPostProcess
+    prior.PriorBoxDecoder / PriorBoxPostProcess
+    predictor.BasePredictor / create_predictor / get_prediction_results
+    runtime.resize_batch / adjust_coordinates
+    parallel.shard_batch / allgather_detections
+"""
+from . import _lib, ops  # noqa: F401
+from .preprocess import Normalize, FlipNormalize, get_preprocess  # noqa: F401
+from .heads import YoloV3Layer, yolo_feature_maps  # noqa: F401
+from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostProcess,  # noqa: F401
+                          BatchedNMSPostProcess, YoloV3PostProcess, YoloV3FusedPostProcess,
+                          NoOpPostProcess, batched_nms, get_postprocess)
+from .prior import PriorBoxDecoder, PriorBoxPostProcess  # noqa: F401
+from .predictor import BasePredictor, create_predictor, get_prediction_results  # noqa: F401
+
+__version__ = "0.1.0"

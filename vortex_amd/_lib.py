@@ -1,0 +1,105 @@
+"""ctypes binding of libvortex_hip.so (include/vortex_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, the product path raises.
+Torch is used for device memory and streams only (plumbing)."""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvortex_hip.so")
+
+VX_OK = 0
+VX_STATUS_NAN = 1
+VX_STATUS_BAD_CLASS = 2
+VX_MAX_CLASSES = 4096
+VX_MAX_CANDIDATES = 1048575
+VX_RESIZE_STRETCH = 0
+VX_RESIZE_LETTERBOX = 1
+
+_F3 = c_float * 3
+_F6 = c_float * 6
+_F18 = c_float * 18
+
+_SIGNATURES = {
+    "vx_version": (c_int, []),
+    "vx_error_string": (ctypes.c_char_p, [c_int]),
+    "vx_preprocess_u8hwc_f32nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                            _F3, _F3, c_int, c_int, c_int, c_int, c_void_p]),
+    "vx_yolo_head_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _F6, c_float,
+                                    c_int64, c_int64, c_void_p]),
+    "vx_yolo_decode_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vx_yolo_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+    "vx_yolo_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vx_yolo_fused_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18,
+                                     c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_prior_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vx_prior_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_batched_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vx_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class VortexHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvortex_hip.so once.  Raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VortexHipError(
+                "libvortex_hip.so not found at %s — build it with `make -C vortex_amd/csrc` "
+                "(or __graft_entry__.build()); vortex_amd has no CPU fallback" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != VX_OK:
+        msg = lib().vx_error_string(code).decode()
+        raise VortexHipError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise VortexHipError(
+            "%s must live on an MI355X device (got %s); vortex_amd runs HIP kernels only" % (name, t.device))
+
+
+def f3(v):
+    v = [float(x) for x in v]
+    if len(v) == 1:
+        v = v * 3
+    return _F3(*v)
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])
+
+
+def f18(v):
+    return _F18(*[float(x) for x in v])

@@ -1,0 +1,89 @@
+// Shared device helpers for libvortex_hip (gfx950 only: wave = 64 lanes).
+// Build with -ffp-contract=off: the decoders and the IoU test must round once per
+// operation, exactly like the reference's fp32 CPU arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vortex_hip.h"
+
+#define VX_WAVE 64
+
+typedef unsigned long long u64;
+
+struct __attribute__((aligned(16))) vx_f4 { float x, y, z, w; };
+typedef float vx_v4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(8)))  vx_f2 { float x, y; };
+struct __attribute__((packed, aligned(4))) vx_u3 { unsigned a, b, c; };
+
+// staging record written by the decode kernels for every surviving row
+//   a = x1,y1,x2,y2   b = score, class_conf, class(bits), row(bits)
+struct __attribute__((aligned(16))) vx_rec { vx_f4 a; vx_f4 b; };
+
+__device__ __forceinline__ int vx_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ int vx_mbcnt(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// sigmoid / exp of the YOLO head decode (tolerance-class: <= ~1e-6 relative).
+// One definition shared by the standalone and the fused kernel so both give the same bits.
+__device__ __forceinline__ float vx_exp(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
+__device__ __forceinline__ float vx_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + vx_exp(-x));
+}
+
+// YoloV3Layer eval arithmetic for one cell (heads/detection/yolov3.py:281-302)
+__device__ __forceinline__ float vx_yolo_xy(float t, float g, float stride) { return (vx_sigmoid(t) + g) * stride; }
+__device__ __forceinline__ float vx_yolo_wh(float t, float a, float stride) { return (vx_exp(t) * a) * stride; }
+
+// YoloV3Decoder arithmetic for one surviving row (postprocess/yolov3.py:63-67, :13-16)
+__device__ __forceinline__ vx_rec vx_yolo_record(float cx, float cy, float w, float h, float obj,
+                                                 float conf, int cls, int row, float img_size) {
+    float bx = cx / img_size, by = cy / img_size, bw = w / img_size, bh = h / img_size;
+    vx_rec r;
+    r.a.x = bx - bw / 2.0f;
+    r.a.y = by - bh / 2.0f;
+    r.a.z = bx + bw / 2.0f;
+    r.a.w = by + bh / 2.0f;
+    r.b.x = obj * conf;
+    r.b.y = conf;
+    r.b.z = __int_as_float(cls);
+    r.b.w = __int_as_float(row);
+    return r;
+}
+
+// descending-score sortable 32-bit image of a float (ties: -0 == +0)
+__device__ __forceinline__ unsigned vx_desc_key(float s) {
+    if (s == 0.0f) s = 0.0f;
+    unsigned u = __float_as_uint(s);
+    unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~asc;
+}
+
+#define VX_KEY_SENTINEL (~0ull)
+// key1 = [cls:12][desc score:32][index:20]
+__device__ __forceinline__ u64 vx_key1(int cls, float score, int idx) {
+    return ((u64)(unsigned)cls << 52) | ((u64)vx_desc_key(score) << 20) | (u64)(unsigned)idx;
+}
+__device__ __forceinline__ int vx_key1_idx(u64 k) { return (int)(k & 0xFFFFFu); }
+__device__ __forceinline__ int vx_key1_cls(u64 k) { return (int)(k >> 52); }
+// key2 = [desc score:32][index:32]  (global keep order: score desc, index asc)
+__device__ __forceinline__ u64 vx_key2_from_key1(u64 k) { return (((k >> 20) & 0xFFFFFFFFull) << 32) | (k & 0xFFFFFu); }
+
+// parameters of the per-image compaction pass shared by all decoders (vx_yolo.hip)
+struct vx_finish_params {
+    int R, tiles_per_img, D, L;           // D = 6 + 2L floats per detection row
+    int uniform_tile_rows;                // >0: row0(t) = t*uniform_tile_rows ; 0: fused YOLO tile table
+};
+int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int *tile_counts, int B,
+                            vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,
+                            int *counts, hipStream_t st);
+
+__host__ __device__ __forceinline__ int vx_next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}

@@ -1,0 +1,469 @@
+// K5-K7 — class-aware batched NMS for all images of a batch in one pass, no host round trip.
+//
+//   vx_k_nms_build_keys : key1 = [class:12][descending score:32][index:20] per candidate
+//   vx_k_sort_local/_global : per-image bitonic sort of 64-bit keys (LDS chunks up to 16384 keys,
+//                         global compare-exchange steps above that); epilogue 1 gathers the
+//                         class-offset boxes into sorted order, epilogue 2 writes the outputs
+//   vx_k_nms_sweep      : per (image, class segment) greedy suppression: 64x64 IoU tiles resolved
+//                         with wavefront ballots; large segments use the block-level sweep
+//                         (wave 0 resolves a tile, all waves apply its kept boxes to later tiles)
+//   second sort         : kept boxes back into global score order (key2 = [score:32][index:32])
+//
+// Reference: networks/modules/postprocess/utils/nms.py:57-98 (batched_nms: offsets = idxs*2049
+// added in fp32, then torchvision.ops.nms), :105-123 (BatchedNMS.forward: index_select by keep).
+// The greedy core follows the oracle's restatement of torchvision's CPU kernel (oracle/nms_oracle.c)
+// operation for operation; ties in score resolve to the lower candidate index.
+//
+// Class segmentation is exact w.r.t. the reference's single class-agnostic pass because boxes of
+// different classes are disjoint after the 2049*cls offset (|coordinate| < 1024) and a zero
+// intersection never exceeds an iou_threshold >= 0.
+#include "vx_common.h"
+
+#define VX_SORT_CHMAX 16384
+#define VX_SWEEP_WT 4                 // wave routine: segments up to 64*WT boxes
+#define VX_ALIVE_WORDS 2048           // block routine: segments up to 64*2048 = 131072 boxes
+#define VX_SWEEP_MAXBIG 128           // large segments queued per workgroup (>= classes per workgroup)
+
+struct vx_nms_params {
+    int B, cap, npad_cap, D, n_classes, top_k, out_cap;
+    float thr;
+};
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restrict__ scores,
+                                                           const long long *__restrict__ cls,
+                                                           const int *__restrict__ counts, vx_nms_params p,
+                                                           u64 *__restrict__ keys1, int *__restrict__ count2,
+                                                           int *__restrict__ status) {
+    int b = blockIdx.y;
+    int n = counts ? min(counts[b], p.cap) : p.cap;
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) count2[b] = 0;
+    if (k < n) {
+        long long c = cls[(long long)b * p.cap + k];
+        if (c < 0 || c >= VX_MAX_CLASSES) { atomicOr(status, VX_STATUS_BAD_CLASS); c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
+        keys1[(long long)b * p.npad_cap + k] = vx_key1((int)c, scores[(long long)b * p.cap + k], k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitonic sort, ascending, of the first npad_b = pow2ceil(n_b) keys of every image (missing keys
+// read as the sentinel, which sorts last).  Direction of each compare-exchange comes from the
+// global index, so LDS-local phases and global steps compose into one network.
+struct vx_sort_params {
+    int stride;        // keys per image (npad_cap)
+    int CH;            // LDS chunk (power of two <= VX_SORT_CHMAX)
+    int k_merge;       // 0: full local sort k=2..CH ; else local tail (j = CH/2..1) of merge stage k
+    int fixed_n;       // used when counts == nullptr
+    int epilogue;      // 0 none, 1 gather offset boxes, 2 write outputs
+};
+struct vx_epi_params {
+    // epilogue 1
+    const float *boxes; vx_f4 *sbox; float *sarea; int cap;
+    // epilogue 2
+    const float *det; long long *keep_idx; float *out_det; int *keep_counts; int D, top_k, out_cap;
+};
+
+__device__ __forceinline__ void vx_cmpx(u64 &a, u64 &b, bool asc) {
+    bool sw = asc ? (a > b) : (a < b);
+    if (sw) { u64 t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, const int *__restrict__ counts,
+                                                        vx_sort_params sp, vx_epi_params ep) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    const int b = blockIdx.y;
+    const int n = counts ? min(counts[b], sp.stride) : sp.fixed_n;
+    const int npad = vx_next_pow2(max(n, 1));
+    const int base = blockIdx.x * sp.CH;
+    if (base >= npad) return;
+    const int m = min(sp.CH, npad);
+    u64 *g = keys + (long long)b * sp.stride + base;
+    const int nt = blockDim.x;
+    if (sp.k_merge == 0) {
+        for (int i = threadIdx.x; i < m; i += nt) sk[i] = (base + i < n) ? g[i] : VX_KEY_SENTINEL;
+    } else {
+        if (sp.k_merge > npad) return;
+        for (int i = threadIdx.x; i < m; i += nt) sk[i] = g[i];
+    }
+    __syncthreads();
+    const int half = m >> 1;
+    const int k_lo = sp.k_merge == 0 ? 2 : sp.k_merge;
+    const int k_hi = sp.k_merge == 0 ? m : sp.k_merge;
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+        for (int j = min(k >> 1, half); j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += nt) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int q = i | j;
+                bool asc = ((base + i) & k) == 0;
+                u64 a = sk[i], c = sk[q];
+                bool sw = asc ? (a > c) : (a < c);
+                if (sw) { sk[i] = c; sk[q] = a; }
+            }
+            __syncthreads();
+        }
+        if (k == 0x40000000) break;
+    }
+    const bool final_stage = (sp.k_merge == 0) ? (npad <= sp.CH) : (sp.k_merge == npad);
+    // keys go back to global (next stage / sweep read them)
+    for (int i = threadIdx.x; i < m; i += nt) g[i] = sk[i];
+    if (!final_stage || sp.epilogue == 0) return;
+    if (sp.epilogue == 1) {
+        // sorted position -> class-offset box  fl32(x + fl32(2049*cls))  (nms.py:94-96) and its area
+        for (int i = threadIdx.x; i < m; i += nt) {
+            int gi = base + i;
+            if (gi < n) {
+                u64 key = sk[i];
+                int idx = vx_key1_idx(key);
+                float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
+                vx_f4 bx = *reinterpret_cast<const vx_f4 *>(ep.boxes + ((long long)b * ep.cap + idx) * 4);
+                bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
+                long long o = (long long)b * sp.stride + gi;
+                ep.sbox[o] = bx;
+                ep.sarea[o] = (bx.z - bx.x) * (bx.w - bx.y);
+            }
+        }
+    } else {
+        int nk = n;
+        if (ep.top_k > 0) nk = min(nk, ep.top_k);
+        nk = min(nk, ep.out_cap);
+        if (base == 0 && threadIdx.x == 0) ep.keep_counts[b] = nk;
+        for (int i = threadIdx.x; i < m; i += nt) {
+            int gi = base + i;
+            if (gi < nk) {
+                int idx = (int)(sk[i] & 0xFFFFFFFFull);
+                ep.keep_idx[(long long)b * ep.out_cap + gi] = idx;
+                const float *s = ep.det + ((long long)b * ep.cap + idx) * ep.D;
+                float *d = ep.out_det + ((long long)b * ep.out_cap + gi) * ep.D;
+                for (int q = 0; q < ep.D; ++q) d[q] = s[q];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void vx_k_sort_global(u64 *__restrict__ keys, const int *__restrict__ counts,
+                                                        int stride, int fixed_n, int k, int j) {
+    const int b = blockIdx.y;
+    const int n = counts ? min(counts[b], stride) : fixed_n;
+    const int npad = vx_next_pow2(max(n, 1));
+    if (k > npad) return;
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (npad >> 1)) return;
+    int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    int q = i | j;
+    u64 *g = keys + (long long)b * stride;
+    bool asc = (i & k) == 0;
+    u64 a = g[i], c = g[q];
+    bool sw = asc ? (a > c) : (a < c);
+    if (sw) { g[i] = c; g[q] = a; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IoU test, operation for operation as oracle/nms_oracle.c (box i = the kept, higher-scoring one).
+__device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
+                                          float jx1, float jy1, float jx2, float jy2, float ja, float thr) {
+    float xx1 = ix1 < jx1 ? jx1 : ix1;
+    float yy1 = iy1 < jy1 ? jy1 : iy1;
+    float xx2 = jx2 < ix2 ? jx2 : ix2;
+    float yy2 = jy2 < iy2 ? jy2 : iy2;
+    float w = xx2 - xx1; w = 0.0f < w ? w : 0.0f;
+    float h = yy2 - yy1; h = 0.0f < h ? h : 0.0f;
+    float inter = w * h;
+    float ovr = inter / (ia + ja - inter);
+    return ovr > thr;
+}
+
+__device__ __forceinline__ float vx_bcast(float v, int lane_uniform) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// first index in [0,n) with keys[idx] >= target; executed by a whole wave (64-ary search)
+__device__ __forceinline__ int vx_lower_bound_wave(const u64 *__restrict__ keys, int n, u64 target) {
+    const int lane = vx_lane();
+    int lo = 0, hi = n;
+    while (hi > lo) {
+        long long len = hi - lo;
+        int pos = lo + (int)(((long long)(lane + 1) * len) / 65);
+        bool ge = keys[pos] >= target;
+        u64 m = __ballot(ge);
+        if (m == 0) {
+            lo = lo + (int)((64LL * len) / 65) + 1;
+        } else {
+            int f = __builtin_ctzll(m);
+            int pf = lo + (int)(((long long)(f + 1) * len) / 65);
+            int pp = f > 0 ? lo + (int)(((long long)f * len) / 65) + 1 : lo;
+            hi = pf;
+            lo = pp;
+        }
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void vx_emit_kept(u64 m, bool mine, u64 key1, u64 *__restrict__ keys2,
+                                             int *__restrict__ count2) {
+    if (m == 0) return;
+    int base = 0;
+    if (vx_lane() == 0) base = atomicAdd(count2, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (mine) keys2[base + vx_mbcnt(m)] = vx_key2_from_key1(key1);
+}
+
+// Wave routine: a segment of n <= 64*WT boxes, everything in registers.
+__device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
+                                              const u64 *__restrict__ keys1, int lo, int n, float thr,
+                                              u64 *__restrict__ keys2, int *__restrict__ count2) {
+    const int lane = vx_lane();
+    float x1[VX_SWEEP_WT], y1[VX_SWEEP_WT], x2[VX_SWEEP_WT], y2[VX_SWEEP_WT], ar[VX_SWEEP_WT];
+    bool alive[VX_SWEEP_WT];
+#pragma unroll
+    for (int u = 0; u < VX_SWEEP_WT; ++u) {
+        int o = u * 64 + lane;
+        alive[u] = o < n;
+        vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+        float a = 0.f;
+        if (alive[u]) { bx = sbox[lo + o]; a = sarea[lo + o]; }
+        x1[u] = bx.x; y1[u] = bx.y; x2[u] = bx.z; y2[u] = bx.w; ar[u] = a;
+    }
+#pragma unroll
+    for (int t = 0; t < VX_SWEEP_WT; ++t) {
+        if (t * 64 < n) {
+            u64 todo = __ballot(alive[t]);
+            while (todo) {
+                int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                float bx1 = vx_bcast(x1[t], i), by1 = vx_bcast(y1[t], i);
+                float bx2 = vx_bcast(x2[t], i), by2 = vx_bcast(y2[t], i), ba = vx_bcast(ar[t], i);
+#pragma unroll
+                for (int u = t; u < VX_SWEEP_WT; ++u) {
+                    if (u * 64 < n) {
+                        bool sup = vx_iou_gt(bx1, by1, bx2, by2, ba, x1[u], y1[u], x2[u], y2[u], ar[u], thr);
+                        if (u == t) sup = sup && (lane > i);
+                        alive[u] = alive[u] && !sup;
+                    }
+                }
+                u64 m = __ballot(alive[t]);
+                todo = m & ~((2ull << i) - 1ull);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VX_SWEEP_WT; ++u) {
+        if (u * 64 < n) {
+            u64 m = __ballot(alive[u]);
+            u64 key = alive[u] ? keys1[lo + u * 64 + lane] : 0ull;
+            vx_emit_kept(m, alive[u], key, keys2, count2);
+        }
+    }
+}
+
+// Block routine: any segment up to 64*VX_ALIVE_WORDS boxes.  Per 64-box tile: wave 0 resolves the
+// tile against itself (serial over its still-alive boxes, one ballot each) and parks the kept boxes
+// in LDS; then every wave applies those kept boxes to its share of the later tiles.
+struct vx_sweep_smem {
+    u64 alive[VX_ALIVE_WORDS];
+    vx_f4 kbox[64];
+    float karea[64];
+    int kcount;
+};
+
+__device__ __forceinline__ void vx_sweep_block(vx_sweep_smem &S, const vx_f4 *__restrict__ sbox,
+                                               const float *__restrict__ sarea, const u64 *__restrict__ keys1,
+                                               int lo, int n, float thr, u64 *__restrict__ keys2,
+                                               int *__restrict__ count2) {
+    const int lane = vx_lane();
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int T = (n + 63) >> 6;
+    for (int w = threadIdx.x; w < T; w += blockDim.x) {
+        int rem = n - w * 64;
+        S.alive[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (wave == 0) {
+            int o = t * 64 + lane;
+            vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+            float a = 0.f;
+            if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
+            u64 al = S.alive[t];
+            u64 todo = al;
+            while (todo) {
+                int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                float bx1 = vx_bcast(bx.x, i), by1 = vx_bcast(bx.y, i);
+                float bx2 = vx_bcast(bx.z, i), by2 = vx_bcast(bx.w, i), ba = vx_bcast(a, i);
+                bool sup = (lane > i) && vx_iou_gt(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
+                al &= ~__ballot(sup);
+                todo = al & ~((2ull << i) - 1ull);
+            }
+            if ((al >> lane) & 1ull) {
+                int pos = vx_mbcnt(al);
+                S.kbox[pos] = bx;
+                S.karea[pos] = a;
+            }
+            if (lane == 0) { S.alive[t] = al; S.kcount = __popcll(al); }
+        }
+        __syncthreads();
+        const int kc = S.kcount;
+        if (kc > 0) {
+            for (int u = t + 1 + wave; u < T; u += nw) {
+                u64 au = S.alive[u];
+                if (au == 0) continue;
+                int o = u * 64 + lane;
+                vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+                float a = 0.f;
+                if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
+                bool al = (au >> lane) & 1ull;
+                for (int q = 0; q < kc; ++q) {
+                    vx_f4 kb = S.kbox[q];
+                    float ka = S.karea[q];
+                    if (vx_iou_gt(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
+                }
+                u64 m = __ballot(al);
+                if (lane == 0) S.alive[u] = m;
+            }
+        }
+        __syncthreads();
+    }
+    for (int w = wave; w < T; w += nw) {
+        u64 m = S.alive[w];
+        bool mine = (m >> lane) & 1ull;
+        u64 key = mine ? keys1[lo + w * 64 + lane] : 0ull;
+        vx_emit_kept(m, mine, key, keys2, count2);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
+                                                      const float *__restrict__ sarea,
+                                                      const int *__restrict__ counts, vx_nms_params p,
+                                                      u64 *__restrict__ keys2, int *__restrict__ count2) {
+    __shared__ vx_sweep_smem S;
+    __shared__ int s_big[VX_SWEEP_MAXBIG][2];
+    __shared__ int s_nbig;
+    const int b = blockIdx.y;
+    const int n = counts ? min(counts[b], p.cap) : p.cap;
+    if (n == 0) return;
+    const long long ob = (long long)b * p.npad_cap;
+    const u64 *k1 = keys1 + ob;
+    const vx_f4 *sb = sbox + ob;
+    const float *sa = sarea + ob;
+    u64 *k2 = keys2 + ob;
+    int *c2 = count2 + b;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int NC = p.n_classes;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    // phase A: groups of nw consecutive classes are dealt round-robin to the image's workgroups;
+    // each wave searches its class segment, sweeps it if small, queues it if large
+    for (int c = blockIdx.x * nw + wave; c < NC; c += gridDim.x * nw) {
+        int lo = vx_lower_bound_wave(k1, n, (u64)c << 52);
+        if (lo >= n) break;                              // no class >= c left (keys ascending)
+        if (vx_key1_cls(k1[lo]) != c) continue;
+        int hi = vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52);
+        int len = hi - lo;
+        if (len <= 64 * VX_SWEEP_WT) {
+            vx_sweep_wave(sb, sa, k1, lo, len, p.thr, k2, c2);
+        } else if (vx_lane() == 0) {
+            int q = atomicAdd(&s_nbig, 1);
+            s_big[q][0] = lo; s_big[q][1] = len;
+        }
+    }
+    __syncthreads();
+    // phase B: large segments, whole workgroup each
+    const int nbig = s_nbig;
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], p.thr, k2, c2);
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline size_t vx_align256n(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; size_t bytes; };
+
+static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
+    vx_nms_ws w;
+    size_t n = (size_t)B * npad_cap;
+    char *p = (char *)ws;
+    size_t off = 0;
+    w.keys1 = (u64 *)(p + off); off += vx_align256n(n * sizeof(u64));
+    w.sbox = (vx_f4 *)(p + off); off += vx_align256n(n * sizeof(vx_f4));
+    w.sarea = (float *)(p + off); off += vx_align256n(n * sizeof(float));
+    w.keys2 = (u64 *)(p + off); off += vx_align256n(n * sizeof(u64));
+    w.count2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t vx_batched_nms_workspace_bytes(int B, int capacity) {
+    if (B <= 0 || capacity <= 0 || capacity > VX_MAX_CANDIDATES) return 0;
+    return vx_nms_carve(nullptr, B, vx_next_pow2(capacity)).bytes;
+}
+
+static int vx_sort_launch(u64 *keys, const int *counts, int fixed_n, int B, int npad_cap, int epilogue,
+                          const vx_epi_params &ep, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int CH = npad_cap < VX_SORT_CHMAX ? npad_cap : VX_SORT_CHMAX;
+    size_t lds = (size_t)CH * sizeof(u64);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
+    if (!attr_set[dev]) {
+        // 16384 keys x 8 B = 128 KiB of the CU's 160 KiB LDS
+        if (hipFuncSetAttribute((const void *)vx_k_sort_local, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
+            return VX_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    int threads = CH / 2 < 1024 ? (CH / 2 < 64 ? 64 : CH / 2) : 1024;
+    vx_sort_params sp;
+    sp.stride = npad_cap; sp.CH = CH; sp.k_merge = 0; sp.fixed_n = fixed_n; sp.epilogue = epilogue;
+    dim3 grid_local(npad_cap / CH, B);
+    hipLaunchKernelGGL(vx_k_sort_local, grid_local, dim3(threads), lds, st, keys, counts, sp, ep);
+    for (long long k = 2LL * CH; k <= npad_cap; k <<= 1) {
+        for (long long j = k >> 1; j >= CH; j >>= 1)
+            hipLaunchKernelGGL(vx_k_sort_global, dim3((npad_cap / 2 + 255) / 256, B), dim3(256), 0, st, keys, counts,
+                               npad_cap, fixed_n, (int)k, (int)j);
+        sp.k_merge = (int)k;
+        hipLaunchKernelGGL(vx_k_sort_local, grid_local, dim3(threads), lds, st, keys, counts, sp, ep);
+    }
+    return VX_OK;
+}
+
+extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
+                              const int32_t *d_counts, int B, int capacity, int D, int n_classes,
+                              float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
+                              int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!d_boxes || !d_scores || !d_cls || !d_det || !d_keep_idx || !d_out_det || !d_keep_counts || !d_status ||
+        !d_workspace)
+        return VX_ERR_INVALID_ARG;
+    if (B <= 0 || capacity <= 0 || D <= 0 || out_capacity <= 0) return VX_ERR_INVALID_ARG;
+    if (!(iou_threshold >= 0.0f)) return VX_ERR_UNSUPPORTED;     // see header: class segmentation needs thr >= 0
+    if (capacity > VX_MAX_CANDIDATES || B > 65535) return VX_ERR_UNSUPPORTED;
+    if (n_classes <= 0 || n_classes > VX_MAX_CLASSES) n_classes = VX_MAX_CLASSES;
+    int need_out = (top_k > 0 && top_k < capacity) ? top_k : capacity;
+    if (out_capacity < need_out) return VX_ERR_INVALID_ARG;
+    if (((uintptr_t)d_boxes & 15) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_cls & 7) ||
+        ((uintptr_t)d_keep_idx & 7))
+        return VX_ERR_ALIGNMENT;
+    int npad_cap = vx_next_pow2(capacity);
+    vx_nms_ws w = vx_nms_carve(d_workspace, B, npad_cap);
+    if (workspace_bytes < w.bytes) return VX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    vx_nms_params p;
+    p.B = B; p.cap = capacity; p.npad_cap = npad_cap; p.D = D; p.n_classes = n_classes; p.top_k = top_k;
+    p.out_cap = out_capacity; p.thr = iou_threshold;
+
+    hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
+                       (const long long *)d_cls, d_counts, p, w.keys1, w.count2, d_status);
+    vx_epi_params ep = {};
+    ep.boxes = d_boxes; ep.sbox = w.sbox; ep.sarea = w.sarea; ep.cap = capacity;
+    ep.det = d_det; ep.keep_idx = (long long *)d_keep_idx; ep.out_det = d_out_det; ep.keep_counts = d_keep_counts;
+    ep.D = D; ep.top_k = top_k; ep.out_cap = out_capacity;
+    int rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
+    if (rc != VX_OK) return rc;
+    int X = (n_classes + 7) / 8;          // 2 class groups of 4 waves per workgroup ...
+    if (X > 32) X = 32;                   // ... capped: 4096 classes / 32 = 128 = VX_SWEEP_MAXBIG
+    if (X < 1) X = 1;
+    hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(256), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
+                       w.count2);
+    rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
+    if (rc != VX_OK) return rc;
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}

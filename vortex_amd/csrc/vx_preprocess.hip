@@ -1,0 +1,192 @@
+// K1 — uint8 NHWC -> fp32 NCHW normalise (+ optional channel flip, + optional bilinear
+// stretch / letterbox resize).  HBM-bound streaming: 3 B in, 12 B out per pixel.
+//
+// Reference: networks/modules/preprocess/normalizer.py:13-31 (to_tensor), :34-60 (normalize),
+// :74-77 / :91-95 (Normalize / FlipNormalize .forward); resize: src/runtime/vortex/runtime/
+// basic_runtime.py:66-68.
+//
+// ((float(v)/scaler) - mean[c]) / std[c] has only 256 x 3 distinct results, so each workgroup
+// builds that table once in LDS with the reference's exact IEEE operation order and the
+// streaming loop is a table lookup: bit-exact by construction, no per-pixel divisions.
+#include "vx_common.h"
+
+struct vx_norm_params { float mean[3]; float std[3]; float scaler; int flip; };
+
+__device__ __forceinline__ void vx_build_lut(float *lut /*[3][256]*/, const vx_norm_params &p) {
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) {
+        int c = i >> 8, v = i & 255;
+        float x = (float)v / p.scaler;          // img.float().div(scaler)      normalizer.py:30
+        x = x - p.mean[c];                      // sub_(mean)                   normalizer.py:59
+        x = x / p.std[c];                       // div_(std)
+        lut[i] = x;
+    }
+    __syncthreads();
+}
+
+// Same-size path.  One thread = 4 consecutive pixels of one image: one 12-byte load,
+// three 16-byte plane stores; a wave reads 768 contiguous bytes and writes 3 x 1 KiB.
+// Requires HW % 4 == 0 (host checks; otherwise the scalar kernel below runs).
+__global__ __launch_bounds__(256) void vx_k_normalize_vec4(const uint8_t *__restrict__ src,
+                                                           float *__restrict__ dst,
+                                                           long long quads_per_img, long long total_quads,
+                                                           vx_norm_params p) {
+    __shared__ float lut[768];
+    vx_build_lut(lut, p);
+    const float *l0 = lut, *l1 = lut + 256, *l2 = lut + 512;
+    const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;      // source byte feeding output channel 0 / 2
+    const long long HW = quads_per_img * 4;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total_quads;
+         q += (long long)gridDim.x * blockDim.x) {
+        long long b = q / quads_per_img;
+        long long p4 = (q - b * quads_per_img) * 4;
+        vx_u3 v = *reinterpret_cast<const vx_u3 *>(src + (b * HW + p4) * 3);
+        unsigned char px[12];
+        *reinterpret_cast<unsigned *>(px + 0) = v.a;
+        *reinterpret_cast<unsigned *>(px + 4) = v.b;
+        *reinterpret_cast<unsigned *>(px + 8) = v.c;
+        vx_v4 o0, o1, o2;
+        o0.x = l0[px[0 + s0]]; o0.y = l0[px[3 + s0]]; o0.z = l0[px[6 + s0]]; o0.w = l0[px[9 + s0]];
+        o1.x = l1[px[1]];      o1.y = l1[px[4]];      o1.z = l1[px[7]];      o1.w = l1[px[10]];
+        o2.x = l2[px[0 + s2]]; o2.y = l2[px[3 + s2]]; o2.z = l2[px[6 + s2]]; o2.w = l2[px[9 + s2]];
+        float *d = dst + (b * 3) * HW + p4;
+        // written once, read later by the backbone: keep it out of the caches
+        __builtin_nontemporal_store(o0, reinterpret_cast<vx_v4 *>(d));
+        __builtin_nontemporal_store(o1, reinterpret_cast<vx_v4 *>(d + HW));
+        __builtin_nontemporal_store(o2, reinterpret_cast<vx_v4 *>(d + 2 * HW));
+    }
+}
+
+// Scalar fallback (HW % 4 != 0 or misaligned pointers): one thread = one pixel.
+__global__ __launch_bounds__(256) void vx_k_normalize_scalar(const uint8_t *__restrict__ src,
+                                                             float *__restrict__ dst,
+                                                             long long HW, long long total_px,
+                                                             vx_norm_params p) {
+    __shared__ float lut[768];
+    vx_build_lut(lut, p);
+    const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_px;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long b = i / HW, pp = i - b * HW;
+        const uint8_t *s = src + i * 3;
+        float *d = dst + b * 3 * HW + pp;
+        d[0] = lut[s[s0]];
+        d[HW] = lut[256 + s[1]];
+        d[2 * HW] = lut[512 + s[s2]];
+    }
+}
+
+// Resize (+normalise).  OpenCV's u8 INTER_LINEAR scheme (see oracle resize_bilinear_u8):
+// half-pixel centres, border-clamped taps, 11-bit fixed-point weights, horizontal pass in
+// int32, vertical pass (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2, then the table.
+// One thread = one output pixel (3 channels); output stores are coalesced per plane, source
+// taps of neighbouring lanes share cache lines.  Letterbox: the image is resized to
+// (nh,nw) and centred; outside pixels take lut[pad_value].
+struct vx_resize_params { int Hs, Ws, Hd, Wd; int nh, nw, top, left; int pad; };
+
+__device__ __forceinline__ void vx_tap(int d, int n_out, int n_in, int &i0, int &i1, int &w0, int &w1) {
+    float scale = (float)n_in / (float)n_out;
+    float f = ((float)d + 0.5f) * scale - 0.5f;
+    float fl = floorf(f);
+    int i = (int)fl;
+    float fr = f - fl;
+    if (i < 0) { i = 0; fr = 0.0f; }
+    if (i >= n_in - 1) { i = n_in - 1; fr = 0.0f; }
+    i0 = i;
+    i1 = min(i + 1, n_in - 1);
+    w1 = (int)rintf(fr * 2048.0f);
+    w0 = 2048 - w1;
+}
+
+__global__ __launch_bounds__(256) void vx_k_resize_normalize(const uint8_t *__restrict__ src,
+                                                             float *__restrict__ dst, int B,
+                                                             vx_resize_params r, vx_norm_params p) {
+    __shared__ float lut[768];
+    vx_build_lut(lut, p);
+    const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;
+    const long long HWd = (long long)r.Hd * r.Wd;
+    const long long total = HWd * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / HWd);
+        int pp = (int)(i - (long long)b * HWd);
+        int y = pp / r.Wd, x = pp - y * r.Wd;
+        int yy = y - r.top, xx = x - r.left;
+        int v0, v1, v2;
+        if (yy < 0 || yy >= r.nh || xx < 0 || xx >= r.nw) {
+            v0 = v1 = v2 = r.pad;
+        } else {
+            int x0, x1, a0, a1, y0, y1, b0, b1;
+            vx_tap(xx, r.nw, r.Ws, x0, x1, a0, a1);
+            vx_tap(yy, r.nh, r.Hs, y0, y1, b0, b1);
+            const uint8_t *s = src + (long long)b * r.Hs * r.Ws * 3;
+            const uint8_t *r0 = s + ((long long)y0 * r.Ws) * 3;
+            const uint8_t *r1 = s + ((long long)y1 * r.Ws) * 3;
+            int out[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+                int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                out[c] = min(max(v, 0), 255);
+            }
+            v0 = out[0]; v1 = out[1]; v2 = out[2];
+        }
+        int c0 = s0 == 0 ? v0 : v2, c2 = s2 == 2 ? v2 : v0;
+        float *d = dst + (long long)b * 3 * HWd + pp;
+        d[0] = lut[c0];
+        d[HWd] = lut[256 + v1];
+        d[2 * HWd] = lut[512 + c2];
+    }
+}
+
+static inline int vx_grid_for(long long work_items, int block, int max_blocks) {
+    long long g = (work_items + block - 1) / block;
+    if (g > max_blocks) g = max_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, int B, int Hs, int Ws,
+                                           int Hd, int Wd, const float mean[3], const float std[3],
+                                           int scaler, int flip, int resize_mode, int pad_value,
+                                           void *stream) {
+    if (!d_src || !d_dst || !mean || !std) return VX_ERR_INVALID_ARG;
+    if (B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || scaler == 0) return VX_ERR_INVALID_ARG;
+    if (resize_mode != VX_RESIZE_STRETCH && resize_mode != VX_RESIZE_LETTERBOX) return VX_ERR_INVALID_ARG;
+    if (pad_value < 0 || pad_value > 255) return VX_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    vx_norm_params p;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean[c]; p.std[c] = std[c]; }
+    p.scaler = (float)scaler;
+    p.flip = flip ? 1 : 0;
+    const int max_blocks = 256 * 8;
+    if (Hs == Hd && Ws == Wd) {
+        long long HW = (long long)Hs * Ws;
+        bool vec = (HW % 4 == 0) && (((uintptr_t)d_src & 3) == 0) && (((uintptr_t)d_dst & 15) == 0);
+        if (vec) {
+            long long qpi = HW / 4, total = qpi * B;
+            hipLaunchKernelGGL(vx_k_normalize_vec4, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
+                               d_src, d_dst, qpi, total, p);
+        } else {
+            long long total = HW * B;
+            hipLaunchKernelGGL(vx_k_normalize_scalar, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
+                               d_src, d_dst, HW, total, p);
+        }
+    } else {
+        vx_resize_params r;
+        r.Hs = Hs; r.Ws = Ws; r.Hd = Hd; r.Wd = Wd; r.pad = pad_value;
+        if (resize_mode == VX_RESIZE_LETTERBOX) {
+            double sc = (double)Hd / Hs < (double)Wd / Ws ? (double)Hd / Hs : (double)Wd / Ws;
+            // python round(): half to even, matches the oracle's int(round(.))
+            r.nh = (int)__builtin_rint(Hs * sc); if (r.nh < 1) r.nh = 1;
+            r.nw = (int)__builtin_rint(Ws * sc); if (r.nw < 1) r.nw = 1;
+            r.top = (Hd - r.nh) / 2; r.left = (Wd - r.nw) / 2;
+        } else {
+            r.nh = Hd; r.nw = Wd; r.top = 0; r.left = 0;
+        }
+        long long total = (long long)Hd * Wd * B;
+        hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
+                           d_src, d_dst, B, r, p);
+    }
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}

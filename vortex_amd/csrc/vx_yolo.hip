@@ -1,0 +1,557 @@
+// K2 / K3 / fused K2+K3 — YOLOv3 head decode and decoder.  HBM-bound streaming kernels.
+//
+//   vx_k_yolo_head_decode  : f32[B,3(5+C),G,G] -> rows of f32[B,R,5+C]   (LDS transpose, both sides coalesced)
+//   vx_k_yolo_decode_rows  : f32[B,R,5+C] -> surviving-row records        (flat 16-B loads into LDS)
+//   vx_k_yolo_fused        : raw heads -> surviving-row records           (channel-major streaming, no LDS)
+//   vx_k_cand_finish       : per image, order-preserving compaction of the per-tile records
+//
+// Reference: networks/modules/heads/detection/yolov3.py:263-304 (YoloV3Layer eval),
+// networks/models/detection/yolov3.py:72-76 (concat), networks/modules/postprocess/yolov3.py:29-68.
+#include "vx_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K2: one workgroup = 64 consecutive cells of one (image, anchor) plane, all 5+C channels.
+// Load: channel-major, 64 consecutive cells per channel (coalesced).  The decoded values go to LDS
+// as the FLAT image of the output rows (cell-major, 5+C floats per row), shifted so that LDS and
+// global addresses agree mod 16 B; the store phase is then a straight 16-B copy of one contiguous
+// 64*(5+C)*4-byte region.  LDS writes have stride 5+C dwords (odd for C=80 -> conflict-free).
+struct vx_head_params {
+    int B, G, cells, NP, tiles_per_plane;
+    float stride;
+    float aw[3], ah[3];
+    long long out_batch_stride, row_offset;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__restrict__ in,
+                                                             float *__restrict__ out, vx_head_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    int blk = blockIdx.x;
+    int t = blk % p.tiles_per_plane;
+    int pa = blk / p.tiles_per_plane;          // b*3 + a
+    int a = pa % 3, b = pa / 3;
+    int cell0 = t * 64;
+    int ncell = min(64, p.cells - cell0);
+    const int NP = p.NP;
+    long long o0 = (long long)b * p.out_batch_stride + (p.row_offset + (long long)a * p.cells + cell0) * NP;
+    int shift = (int)(o0 & 3);
+    const float *plane = in + (long long)pa * NP * p.cells + cell0;
+    const float aw = p.aw[a], ah = p.ah[a], stride = p.stride;
+
+    if (VEC) {
+        // cells % 4 == 0: quads of 4 consecutive cells of one channel (16-B loads)
+        int nq = NP * 16;
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            int ch = q >> 4, c4 = (q & 15) * 4;
+            if (c4 < ncell) {
+                vx_f4 v = *reinterpret_cast<const vx_f4 *>(plane + (long long)ch * p.cells + c4);
+                float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int gc = cell0 + c4 + j;
+                    float x = r[j], y;
+                    if (ch == 0) y = vx_yolo_xy(x, (float)(gc % p.G), stride);
+                    else if (ch == 1) y = vx_yolo_xy(x, (float)(gc / p.G), stride);
+                    else if (ch == 2) y = vx_yolo_wh(x, aw, stride);
+                    else if (ch == 3) y = vx_yolo_wh(x, ah, stride);
+                    else y = vx_sigmoid(x);
+                    tile[shift + (c4 + j) * NP + ch] = y;
+                }
+            }
+        }
+    } else {
+        int ne = NP * 64;
+        for (int e = threadIdx.x; e < ne; e += 256) {
+            int ch = e >> 6, c = e & 63;
+            if (c < ncell) {
+                int gc = cell0 + c;
+                float x = plane[(long long)ch * p.cells + c], y;
+                if (ch == 0) y = vx_yolo_xy(x, (float)(gc % p.G), stride);
+                else if (ch == 1) y = vx_yolo_xy(x, (float)(gc / p.G), stride);
+                else if (ch == 2) y = vx_yolo_wh(x, aw, stride);
+                else if (ch == 3) y = vx_yolo_wh(x, ah, stride);
+                else y = vx_sigmoid(x);
+                tile[shift + c * NP + ch] = y;
+            }
+        }
+    }
+    __syncthreads();
+    // flat copy LDS -> global: global float index o0 - shift + i  <->  tile[i]
+    int n = ncell * NP;
+    int nchunk = (shift + n + 3) >> 2;
+    float *gbase = out + (o0 - shift);
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+        int i = k * 4;
+        if (i >= shift && i + 4 <= shift + n) {
+            *reinterpret_cast<vx_f4 *>(gbase + i) = *reinterpret_cast<const vx_f4 *>(tile + i);
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j >= shift && i + j < shift + n) gbase[i + j] = tile[i + j];
+        }
+    }
+}
+
+extern "C" int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G, int C,
+                                   const float anchor_wh[6], float stride, int64_t out_batch_stride,
+                                   int64_t row_offset, void *stream) {
+    if (!d_in || !d_out || !anchor_wh) return VX_ERR_INVALID_ARG;
+    if (B <= 0 || G <= 0 || C < 0 || out_batch_stride <= 0 || row_offset < 0) return VX_ERR_INVALID_ARG;
+    int NP = 5 + C;
+    if (NP > 255) return VX_ERR_UNSUPPORTED;
+    if (((uintptr_t)d_out & 15) || ((uintptr_t)d_in & 3)) return VX_ERR_ALIGNMENT;
+    long long cells = (long long)G * G;
+    if ((row_offset + 3 * cells) * NP > out_batch_stride) return VX_ERR_INVALID_ARG;
+    vx_head_params p;
+    p.B = B; p.G = G; p.cells = (int)cells; p.NP = NP;
+    p.tiles_per_plane = (int)((cells + 63) / 64);
+    p.stride = stride;
+    for (int a = 0; a < 3; ++a) { p.aw[a] = anchor_wh[2 * a]; p.ah[a] = anchor_wh[2 * a + 1]; }
+    p.out_batch_stride = out_batch_stride; p.row_offset = row_offset;
+    long long nblk = (long long)B * 3 * p.tiles_per_plane;
+    if (nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+    size_t lds = (size_t)(64 * NP + 4) * sizeof(float);
+    bool vec = (cells % 4 == 0) && (((uintptr_t)d_in & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL(vx_k_yolo_head_decode<true>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
+    else     hipLaunchKernelGGL(vx_k_yolo_head_decode<false>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Staging layout shared by the three decoders.  Rows of an image are cut into tiles in row order;
+// tile t owns rows [row0(t), row0(t)+n).  Its survivors are written, in row order, at
+// stage[b][row0(t) + 0 .. count-1] and tile_counts[b][t] = count.  vx_k_cand_finish then scans the
+// counts per image and packs the records densely (order-preserving), producing the four tensors
+// the reference's decoder returns.
+
+// K3: tile = 64 rows.  The tile's 64*(5+C) floats are one contiguous region: 16-B loads into LDS
+// (same shift trick as K2), NaN test on the way; 4 lanes per row scan the classes (first max wins);
+// wave 0 thresholds, ballots and writes the records.
+struct vx_rows_params {
+    int B, R, C, NP, tiles_per_img;
+    float img_size, thr;
+    int use_thr;
+};
+
+__global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__restrict__ pred,
+                                                             vx_rec *__restrict__ stage,
+                                                             int *__restrict__ tile_counts,
+                                                             int *__restrict__ status, vx_rows_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ float s_conf[64];
+    __shared__ int s_cls[64];
+    int t = blockIdx.x % p.tiles_per_img, b = blockIdx.x / p.tiles_per_img;
+    int row0 = t * 64;
+    int nrow = min(64, p.R - row0);
+    const int NP = p.NP;
+    long long o0 = ((long long)b * p.R + row0) * NP;
+    int shift = (int)(o0 & 3);
+    int n = nrow * NP;
+    int nchunk = (shift + n + 3) >> 2;
+    const float *gbase = pred + (o0 - shift);
+    bool nan = false;
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+        int i = k * 4;
+        if (i >= shift && i + 4 <= shift + n) {
+            vx_f4 v = *reinterpret_cast<const vx_f4 *>(gbase + i);
+            nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            *reinterpret_cast<vx_f4 *>(tile + i) = v;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j >= shift && i + j < shift + n) {
+                    float v = gbase[i + j];
+                    nan |= (v != v);
+                    tile[i + j] = v;
+                }
+        }
+    }
+    if (__ballot(nan) != 0 && vx_lane() == 0) atomicOr(status, VX_STATUS_NAN);
+    __syncthreads();
+    // class max / argmax: 4 lanes per row, interleaved classes, first max wins
+    {
+        int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        if (r < nrow) {
+            const float *row = tile + shift + r * NP + 5;
+            for (int k = q; k < p.C; k += 4) {
+                float v = row[k];
+                if (v > best || bi == 0x7fffffff) { best = v; bi = k; }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m <= 2; m <<= 1) {
+            float ob = __shfl_xor(best, m);
+            int oi = __shfl_xor(bi, m);
+            if (ob > best || (ob == best && oi < bi) || (bi == 0x7fffffff && oi != 0x7fffffff)) { best = ob; bi = oi; }
+        }
+        if (q == 0 && r < nrow) { s_conf[r] = best; s_cls[r] = bi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int r = threadIdx.x;
+        bool pass = false;
+        float obj = 0.f;
+        const float *row = tile + shift + r * NP;
+        if (r < nrow) {
+            obj = row[4];
+            pass = p.use_thr ? (obj > p.thr) : true;          // postprocess/yolov3.py:44 (strict, objectness only)
+        }
+        u64 m = __ballot(pass);
+        if (pass) {
+            int pos = vx_mbcnt(m);
+            vx_rec rec = vx_yolo_record(row[0], row[1], row[2], row[3], obj, s_conf[r], s_cls[r], row0 + r, p.img_size);
+            stage[(long long)b * p.R + row0 + pos] = rec;
+        }
+        if (r == 0) tile_counts[(long long)b * p.tiles_per_img + t] = __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused K2+K3.  Work item = one wave = one tile of consecutive cells of one (image, scale, anchor)
+// plane.  Lane = 4 consecutive cells (16-B loads, 1 KiB per wave-instruction) when G*G % 4 == 0,
+// else 1 cell.  The wave walks the 5+C channel planes once, keeping per cell the raw box/objectness
+// logits and the running (max sigmoid, first index) over classes — the [B,R,5+C] tensor is never
+// written.  Survivors are ballot-compacted inside the tile (order-preserving).
+struct vx_scale_desc {
+    const float *ptr;
+    int G, cells, vec, tile_cells, tiles_per_plane;
+    int tile_base;      // first tile index of this scale within an image
+    int row_base;       // first output row of this scale
+    float stride;
+    float aw[3], ah[3];
+};
+struct vx_fused_params {
+    vx_scale_desc s[3];
+    int B, C, NP, R, tiles_per_img;
+    float img_size, thr;
+    int use_thr;
+};
+
+__device__ __forceinline__ int vx_fused_tile_row0(const vx_fused_params &p, int t, int &si, int &a, int &cell0) {
+    si = (t >= p.s[2].tile_base) ? 2 : (t >= p.s[1].tile_base ? 1 : 0);
+    const vx_scale_desc &s = p.s[si];
+    int tt = t - s.tile_base;
+    a = tt / s.tiles_per_plane;
+    cell0 = (tt - a * s.tiles_per_plane) * s.tile_cells;
+    return s.row_base + a * s.cells + cell0;
+}
+
+template <int V>
+__device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx_scale_desc &s, int b, int a,
+                                              int cell0, int row0, int tile, vx_rec *stage, int *tile_counts,
+                                              int *status) {
+    const int lane = vx_lane();
+    const int c0 = cell0 + lane * V;                 // first cell of this lane
+    const bool live = c0 < s.cells;                  // cells % V == 0 -> all V cells live or none
+    const float *plane = s.ptr + ((long long)(b * 3 + a) * p.NP) * s.cells + c0;
+    float tb[5][V];
+    float best[V];
+    int bi[V];
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    if (live) {
+#pragma unroll
+        for (int ch = 0; ch < 5; ++ch) {
+            if (V == 4) {
+                vx_f4 v = *reinterpret_cast<const vx_f4 *>(plane + (long long)ch * s.cells);
+                tb[ch][0] = v.x; tb[ch][1 % V] = v.y; tb[ch][2 % V] = v.z; tb[ch][3 % V] = v.w;
+            } else {
+                tb[ch][0] = plane[(long long)ch * s.cells];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) nan |= (tb[ch][j] != tb[ch][j]);
+        }
+        const float *cp = plane + 5LL * s.cells;
+#pragma unroll 8
+        for (int k = 0; k < p.C; ++k) {
+            float v[V];
+            if (V == 4) {
+                vx_f4 q = *reinterpret_cast<const vx_f4 *>(cp + (long long)k * s.cells);
+                v[0] = q.x; v[1 % V] = q.y; v[2 % V] = q.z; v[3 % V] = q.w;
+            } else {
+                v[0] = cp[(long long)k * s.cells];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                nan |= (v[j] != v[j]);
+                float sg = vx_sigmoid(v[j]);
+                if (sg > best[j] || k == 0) { best[j] = sg; bi[j] = k; }
+            }
+        }
+    }
+    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    float obj[V];
+    bool pass[V];
+    u64 m[V];
+    int below = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        obj[j] = live ? vx_sigmoid(tb[4][j]) : 0.f;
+        pass[j] = live && (p.use_thr ? (obj[j] > p.thr) : true);
+        m[j] = __ballot(pass[j]);
+        below += vx_mbcnt(m[j]);
+        total += __popcll(m[j]);
+    }
+    int pos = below;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        if (pass[j]) {
+            int gc = c0 + j;
+            float cx = vx_yolo_xy(tb[0][j], (float)(gc % s.G), s.stride);
+            float cy = vx_yolo_xy(tb[1][j], (float)(gc / s.G), s.stride);
+            float w = vx_yolo_wh(tb[2][j], s.aw[a], s.stride);
+            float h = vx_yolo_wh(tb[3][j], s.ah[a], s.stride);
+            int row = row0 + lane * V + j;
+            stage[(long long)b * p.R + row0 + pos] = vx_yolo_record(cx, cy, w, h, obj[j], best[j], bi[j], row, p.img_size);
+            ++pos;
+        }
+    }
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
+}
+
+__global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
+                                                       int *__restrict__ tile_counts, int *__restrict__ status) {
+    long long wtile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long total = (long long)p.B * p.tiles_per_img;
+    if (wtile >= total) return;
+    int b = (int)(wtile / p.tiles_per_img);
+    int t = (int)(wtile - (long long)b * p.tiles_per_img);
+    int si, a, cell0;
+    int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
+    // wave-uniform dispatch on the scale's vector width
+    if (si == 0) {
+        if (p.s[0].vec) vx_fused_tile<4>(p, p.s[0], b, a, cell0, row0, t, stage, tile_counts, status);
+        else vx_fused_tile<1>(p, p.s[0], b, a, cell0, row0, t, stage, tile_counts, status);
+    } else if (si == 1) {
+        if (p.s[1].vec) vx_fused_tile<4>(p, p.s[1], b, a, cell0, row0, t, stage, tile_counts, status);
+        else vx_fused_tile<1>(p, p.s[1], b, a, cell0, row0, t, stage, tile_counts, status);
+    } else {
+        if (p.s[2].vec) vx_fused_tile<4>(p, p.s[2], b, a, cell0, row0, t, stage, tile_counts, status);
+        else vx_fused_tile<1>(p, p.s[2], b, a, cell0, row0, t, stage, tile_counts, status);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finish: one workgroup per image.  Exclusive scan of the image's tile counts (256 tiles per round),
+// then every record of the round is copied to its dense position (binary search of the scanned
+// offsets in LDS).  Writes the decoder's four outputs + the count.
+__device__ __forceinline__ int vx_block_excl_scan256(int v, int *s_wave, int &total) {
+    // 256 threads = 4 waves
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[w] = x;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += s_wave[i];
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void vx_k_cand_finish(const vx_rec *__restrict__ stage,
+                                                        const float *__restrict__ stage_lmk,
+                                                        const int *__restrict__ tile_counts,
+                                                        vx_fused_params fp, vx_finish_params p,
+                                                        float *__restrict__ boxes, float *__restrict__ scores,
+                                                        long long *__restrict__ cls, float *__restrict__ det,
+                                                        int *__restrict__ counts) {
+    __shared__ int s_off[257];
+    __shared__ int s_row0[256];
+    __shared__ int s_wave[4];
+    int b = blockIdx.x;
+    int running = 0;
+    for (int t0 = 0; t0 < p.tiles_per_img; t0 += 256) {
+        int t = t0 + threadIdx.x;
+        int c = 0, row0 = 0;
+        if (t < p.tiles_per_img) {
+            c = tile_counts[(long long)b * p.tiles_per_img + t];
+            if (p.uniform_tile_rows > 0) row0 = t * p.uniform_tile_rows;
+            else { int si, a, cell0; row0 = vx_fused_tile_row0(fp, t, si, a, cell0); }
+        }
+        int total;
+        int ex = vx_block_excl_scan256(c, s_wave, total);
+        s_off[threadIdx.x] = ex;
+        s_row0[threadIdx.x] = row0;
+        if (threadIdx.x == 0) s_off[256] = total;
+        __syncthreads();
+        for (int j = threadIdx.x; j < total; j += 256) {
+            // largest tile index lt with s_off[lt] <= j
+            int lo = 0, hi = 256;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= j) lo = mid; else hi = mid;
+            }
+            int i = j - s_off[lo];
+            long long src = (long long)b * p.R + s_row0[lo] + i;
+            long long dst = (long long)b * p.R + running + j;
+            vx_rec r = stage[src];
+            *reinterpret_cast<vx_f4 *>(boxes + dst * 4) = r.a;
+            scores[dst] = r.b.x;
+            int ci = __float_as_int(r.b.z);
+            cls[dst] = (long long)ci;
+            float *d = det + dst * p.D;
+            d[0] = r.a.x; d[1] = r.a.y; d[2] = r.a.z; d[3] = r.a.w;
+            d[4] = r.b.y; d[5] = (float)ci;
+            if (p.L > 0) {
+                const float *lm = stage_lmk + src * (2 * p.L);
+                for (int q = 0; q < 2 * p.L; ++q) d[6 + q] = lm[q];
+            }
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[b] = running;
+}
+
+int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int *tile_counts, int B,
+                            vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,
+                            int *counts, hipStream_t st) {
+    vx_fused_params fp = {};
+    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, (const vx_rec *)stage, stage_lmk, tile_counts, fp,
+                       f, boxes, scores, cls, det, counts);
+    return VX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline size_t vx_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t vx_stage_bytes(int B, int R, int tiles_per_img, int L) {
+    size_t n = vx_align256((size_t)B * R * sizeof(vx_rec));
+    n += vx_align256((size_t)B * tiles_per_img * sizeof(int));
+    if (L > 0) n += vx_align256((size_t)B * R * 2 * L * sizeof(float));
+    return n;
+}
+
+extern "C" size_t vx_yolo_decode_workspace_bytes(int B, int R) {
+    if (B <= 0 || R <= 0) return 0;
+    return vx_stage_bytes(B, R, (R + 63) / 64, 0);
+}
+
+extern "C" int vx_yolo_decode(const float *d_pred, int B, int R, int C, float img_size, float score_threshold,
+                              int use_threshold, float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                              int32_t *d_counts, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                              void *stream) {
+    if (!d_pred || !d_boxes || !d_scores || !d_cls || !d_det || !d_counts || !d_status || !d_workspace)
+        return VX_ERR_INVALID_ARG;
+    if (B <= 0 || R <= 0 || C <= 0) return VX_ERR_INVALID_ARG;
+    int NP = 5 + C;
+    if (NP > 248 || C > VX_MAX_CLASSES || R > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
+    if (((uintptr_t)d_pred & 15) || ((uintptr_t)d_boxes & 15) || ((uintptr_t)d_workspace & 255) ||
+        ((uintptr_t)d_det & 3) || ((uintptr_t)d_cls & 7))
+        return VX_ERR_ALIGNMENT;
+    int tiles = (R + 63) / 64;
+    if (workspace_bytes < vx_stage_bytes(B, R, tiles, 0)) return VX_ERR_WORKSPACE;
+    if ((long long)B * tiles > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+    vx_rec *stage = (vx_rec *)d_workspace;
+    int *tile_counts = (int *)((char *)d_workspace + vx_align256((size_t)B * R * sizeof(vx_rec)));
+    hipStream_t st = (hipStream_t)stream;
+    vx_rows_params p;
+    p.B = B; p.R = R; p.C = C; p.NP = NP; p.tiles_per_img = tiles;
+    p.img_size = img_size; p.thr = score_threshold; p.use_thr = use_threshold ? 1 : 0;
+    size_t lds = (size_t)(64 * NP + 4) * sizeof(float);
+    hipLaunchKernelGGL(vx_k_yolo_decode_rows, dim3((unsigned)(B * tiles)), dim3(256), lds, st, d_pred, stage,
+                       tile_counts, d_status, p);
+    vx_fused_params fp = {};
+    vx_finish_params f;
+    f.R = R; f.tiles_per_img = tiles; f.D = 6; f.L = 0; f.uniform_tile_rows = 64;
+    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, fp, f,
+                       d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+static int vx_fused_setup(vx_fused_params &p, const float *h0, const float *h1, const float *h2, int B, int S,
+                          int C, const float anchors_px[18]) {
+    const float *ptrs[3] = {h0, h1, h2};
+    const int div[3] = {32, 16, 8};
+    const int mask[3][3] = {{6, 7, 8}, {3, 4, 5}, {0, 1, 2}};   // heads/detection/yolov3.py:319-343
+    int tile_base = 0, row_base = 0;
+    for (int i = 0; i < 3; ++i) {
+        vx_scale_desc &s = p.s[i];
+        s.ptr = ptrs[i];
+        s.G = S / div[i];
+        if (s.G <= 0) return VX_ERR_INVALID_ARG;
+        s.cells = s.G * s.G;
+        s.vec = (s.cells % 4 == 0) && (((uintptr_t)ptrs[i] & 15) == 0);
+        s.tile_cells = s.vec ? 256 : 64;
+        s.tiles_per_plane = (s.cells + s.tile_cells - 1) / s.tile_cells;
+        s.tile_base = tile_base;
+        s.row_base = row_base;
+        // stride = img_size / max(grids) as an fp32 tensor (heads/detection/yolov3.py:236)
+        s.stride = (float)((double)S / (double)s.G);
+        for (int a = 0; a < 3; ++a) {
+            // anchor_wh = anchors / stride in fp32 (heads/detection/yolov3.py:244)
+            s.aw[a] = anchors_px[2 * mask[i][a]] / s.stride;
+            s.ah[a] = anchors_px[2 * mask[i][a] + 1] / s.stride;
+        }
+        tile_base += 3 * s.tiles_per_plane;
+        row_base += 3 * s.cells;
+    }
+    p.B = B; p.C = C; p.NP = 5 + C; p.R = row_base; p.tiles_per_img = tile_base;
+    return VX_OK;
+}
+
+static int vx_fused_tiles(int S) {
+    int tiles = 0;
+    const int div[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) {
+        int G = S / div[i], cells = G * G;
+        int tc = (cells % 4 == 0) ? 256 : 64;
+        // a misaligned head pointer falls back to 64-cell tiles: size for the finer tiling
+        tiles += 3 * ((cells + 63) / 64);
+        (void)tc;
+    }
+    return tiles;
+}
+
+static int vx_yolo_rows(int S) {
+    int R = 0;
+    const int div[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) { int G = S / div[i]; R += 3 * G * G; }
+    return R;
+}
+
+extern "C" size_t vx_yolo_fused_workspace_bytes(int B, int S) {
+    if (B <= 0 || S < 32) return 0;
+    return vx_stage_bytes(B, vx_yolo_rows(S), vx_fused_tiles(S), 0);
+}
+
+extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                                    int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                                    float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                                    int32_t *d_counts, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream) {
+    if (!d_head0 || !d_head1 || !d_head2 || !anchors_px || !d_boxes || !d_scores || !d_cls || !d_det ||
+        !d_counts || !d_status || !d_workspace)
+        return VX_ERR_INVALID_ARG;
+    if (B <= 0 || S < 32 || C <= 0) return VX_ERR_INVALID_ARG;
+    if (C > VX_MAX_CLASSES) return VX_ERR_UNSUPPORTED;
+    if (((uintptr_t)d_head0 & 3) || ((uintptr_t)d_head1 & 3) || ((uintptr_t)d_head2 & 3) ||
+        ((uintptr_t)d_boxes & 15) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_det & 3) ||
+        ((uintptr_t)d_cls & 7))
+        return VX_ERR_ALIGNMENT;
+    vx_fused_params p = {};
+    int rc = vx_fused_setup(p, d_head0, d_head1, d_head2, B, S, C, anchors_px);
+    if (rc != VX_OK) return rc;
+    if (p.R > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
+    p.img_size = (float)S; p.thr = score_threshold; p.use_thr = use_threshold ? 1 : 0;
+    if (workspace_bytes < vx_stage_bytes(B, p.R, vx_fused_tiles(S), 0)) return VX_ERR_WORKSPACE;
+    vx_rec *stage = (vx_rec *)d_workspace;
+    int *tile_counts = (int *)((char *)d_workspace + vx_align256((size_t)B * p.R * sizeof(vx_rec)));
+    long long waves = (long long)B * p.tiles_per_img;
+    long long nblk = (waves + 3) / 4;
+    if (nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vx_k_yolo_fused, dim3((unsigned)nblk), dim3(256), 0, st, p, stage, tile_counts, d_status);
+    vx_finish_params f;
+    f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;
+    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, p, f,
+                       d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}

@@ -1,0 +1,201 @@
+"""Functional layer: torch tensors in, libvortex_hip.so calls, torch tensors out.
+
+Every function launches on torch's current stream, allocates its outputs/workspace with
+torch (device memory plumbing) and performs NO host synchronisation; the nn.Module layer
+(preprocess.py / heads.py / postprocess.py / prior.py) does the single D2H read of the
+counts + status words where the reference's API needs Python-visible shapes."""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+COCO_ANCHORS = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45),
+                (59, 119), (116, 90), (156, 198), (373, 326)]   # reference networks/models/detection/yolov3.py:26-29
+
+
+def yolo_rows(img_size: int) -> int:
+    return 3 * sum((img_size // d) ** 2 for d in (32, 16, 8))
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    # torch's caching allocator returns >=512-byte aligned blocks
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------- K1
+def preprocess(img: torch.Tensor, mean: Sequence[float], std: Sequence[float], scaler: int = 255,
+               flip: bool = False, out_size: Optional[Tuple[int, int]] = None,
+               letterbox: bool = False, pad_value: int = 0) -> torch.Tensor:
+    """u8[B,H,W,3] -> f32[B,3,Hd,Wd]; see vx_preprocess_u8hwc_f32nchw."""
+    L.require_cuda(img, "input")
+    assert img.dtype == torch.uint8 and img.dim() == 4 and img.size(3) == 3
+    img = img.contiguous()
+    B, Hs, Ws, _ = img.shape
+    Hd, Wd = (Hs, Ws) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    out = torch.empty((B, 3, Hd, Wd), dtype=torch.float32, device=img.device)
+    rc = L.lib().vx_preprocess_u8hwc_f32nchw(
+        img.data_ptr(), out.data_ptr(), B, Hs, Ws, Hd, Wd, L.f3(mean), L.f3(std), int(scaler),
+        int(bool(flip)), L.VX_RESIZE_LETTERBOX if letterbox else L.VX_RESIZE_STRETCH, int(pad_value),
+        L.stream_ptr(img.device))
+    L.check(rc, "vx_preprocess_u8hwc_f32nchw")
+    return out
+
+
+# --------------------------------------------------------------------------------------- K2
+def yolo_head_decode(x: torch.Tensor, anchor_wh: Sequence[float], stride: float,
+                     out: Optional[torch.Tensor] = None, row_offset: int = 0) -> torch.Tensor:
+    """f32[B,3(5+C),G,G] -> rows [row_offset, row_offset+3GG) of out f32[B,R,5+C]."""
+    L.require_cuda(x, "prediction")
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.size(2) == x.size(3)
+    x = x.contiguous()
+    B, ch, G, _ = x.shape
+    assert ch % 3 == 0
+    NP = ch // 3
+    if out is None:
+        out = torch.empty((B, 3 * G * G, NP), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.size(0) == B and out.size(2) == NP
+    rc = L.lib().vx_yolo_head_decode(x.data_ptr(), out.data_ptr(), B, G, NP - 5, L.f6(anchor_wh), float(stride),
+                                     out.size(1) * NP, int(row_offset), L.stream_ptr(x.device))
+    L.check(rc, "vx_yolo_head_decode")
+    return out
+
+
+class Candidates:
+    """Dense per-image candidate lists produced by a decoder (device buffers, capacity R)."""
+    __slots__ = ("boxes", "scores", "cls", "det", "meta", "B", "R", "D")
+
+    def __init__(self, B, R, D, device):
+        self.B, self.R, self.D = B, R, D
+        self.boxes = torch.empty((B, R, 4), dtype=torch.float32, device=device)
+        self.scores = torch.empty((B, R), dtype=torch.float32, device=device)
+        self.cls = torch.empty((B, R), dtype=torch.int64, device=device)
+        self.det = torch.empty((B, R, D), dtype=torch.float32, device=device)
+        # meta = counts[B] | keep_counts[B] | status[1]  (one D2H copy reads everything)
+        self.meta = torch.zeros((2 * B + 1,), dtype=torch.int32, device=device)
+
+    @property
+    def counts(self):
+        return self.meta[:self.B]
+
+    @property
+    def keep_counts(self):
+        return self.meta[self.B:2 * self.B]
+
+    @property
+    def status(self):
+        return self.meta[2 * self.B:]
+
+
+# --------------------------------------------------------------------------------------- K3
+def yolo_decode(pred: torch.Tensor, img_size: float, score_threshold: float, use_threshold: bool = True) -> Candidates:
+    L.require_cuda(pred, "predictions")
+    assert pred.dtype == torch.float32 and pred.dim() == 3
+    pred = pred.contiguous()
+    B, R, NP = pred.shape
+    c = Candidates(B, R, 6, pred.device)
+    nb = L.lib().vx_yolo_decode_workspace_bytes(B, R)
+    ws = _ws(nb, pred.device)
+    rc = L.lib().vx_yolo_decode(pred.data_ptr(), B, R, NP - 5, float(img_size), float(score_threshold),
+                                int(bool(use_threshold)), c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(),
+                                c.det.data_ptr(), c.counts.data_ptr(), c.status.data_ptr(), ws.data_ptr(), nb,
+                                L.stream_ptr(pred.device))
+    L.check(rc, "vx_yolo_decode")
+    return c
+
+
+# --------------------------------------------------------------------------------------- K2+K3 fused
+def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float,
+                      use_threshold: bool = True, anchors=COCO_ANCHORS) -> Candidates:
+    """heads: raw conv outputs for G = S/32, S/16, S/8 (coarse -> fine)."""
+    assert len(heads) == 3
+    hs = []
+    for h, d in zip(heads, (32, 16, 8)):
+        L.require_cuda(h, "head")
+        assert h.dtype == torch.float32 and h.dim() == 4 and h.size(2) == img_size // d == h.size(3)
+        hs.append(h.contiguous())
+    B, ch = hs[0].shape[:2]
+    C = ch // 3 - 5
+    R = yolo_rows(img_size)
+    c = Candidates(B, R, 6, hs[0].device)
+    nb = L.lib().vx_yolo_fused_workspace_bytes(B, int(img_size))
+    ws = _ws(nb, hs[0].device)
+    flat = [float(v) for a in anchors for v in a]
+    rc = L.lib().vx_yolo_fused_decode(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C,
+                                      L.f18(flat), float(score_threshold), int(bool(use_threshold)),
+                                      c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(), c.det.data_ptr(),
+                                      c.counts.data_ptr(), c.status.data_ptr(), ws.data_ptr(), nb,
+                                      L.stream_ptr(hs[0].device))
+    L.check(rc, "vx_yolo_fused_decode")
+    return c
+
+
+# --------------------------------------------------------------------------------------- K4
+def prior_decode(inp: torch.Tensor, priors: torch.Tensor, n_landmarks: int, score_threshold: float,
+                 use_threshold: bool = True, variances=(0.1, 0.2)) -> Candidates:
+    L.require_cuda(inp, "input")
+    L.require_cuda(priors, "priors")
+    assert inp.dtype == torch.float32 and inp.dim() == 3 and priors.dtype == torch.float32
+    inp = inp.contiguous()
+    priors = priors.contiguous()
+    B, P, ncol = inp.shape
+    assert priors.shape == (P, 4)
+    n_logits = ncol - 4 - 2 * n_landmarks
+    c = Candidates(B, P, 6 + 2 * n_landmarks, inp.device)
+    nb = L.lib().vx_prior_decode_workspace_bytes(B, P, n_landmarks)
+    ws = _ws(nb, inp.device)
+    rc = L.lib().vx_prior_decode(inp.data_ptr(), priors.data_ptr(), B, P, n_landmarks, n_logits,
+                                 float(variances[0]), float(variances[1]), float(score_threshold),
+                                 int(bool(use_threshold)), c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(),
+                                 c.det.data_ptr(), c.counts.data_ptr(), c.status.data_ptr(), ws.data_ptr(), nb,
+                                 L.stream_ptr(inp.device))
+    L.check(rc, "vx_prior_decode")
+    return c
+
+
+# --------------------------------------------------------------------------------------- K5-K7
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor, det: torch.Tensor,
+                counts: Optional[torch.Tensor], iou_threshold: float, n_classes: int = 0,
+                top_k: Optional[int] = None, meta: Optional[torch.Tensor] = None):
+    """boxes f32[B,K,4], scores f32[B,K], cls i64[B,K], det f32[B,K,D], counts i32[B] or None.
+    Returns keep_idx i64[B,out_cap], out_det f32[B,out_cap,D], keep_counts i32[B], status i32[1]
+    (device tensors; rows beyond keep_counts[b] are undefined)."""
+    for t, n in ((boxes, "bboxes"), (scores, "scores"), (cls, "class_indexes"), (det, "detections")):
+        L.require_cuda(t, n)
+    assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and det.dtype == torch.float32
+    assert cls.dtype == torch.int64
+    boxes, scores, cls, det = boxes.contiguous(), scores.contiguous(), cls.contiguous(), det.contiguous()
+    B, K = scores.shape
+    D = det.size(2)
+    assert boxes.shape == (B, K, 4) and cls.shape == (B, K) and det.shape[:2] == (B, K)
+    dev = boxes.device
+    tk = int(top_k) if top_k else 0
+    out_cap = min(K, tk) if tk > 0 else K
+    keep_idx = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
+    out_det = torch.empty((B, out_cap, D), dtype=torch.float32, device=dev)
+    if meta is None:
+        meta = torch.zeros((2 * B + 1,), dtype=torch.int32, device=dev)
+    keep_counts, status = meta[B:2 * B], meta[2 * B:]
+    nb = L.lib().vx_batched_nms_workspace_bytes(B, K)
+    ws = _ws(nb, dev)
+    rc = L.lib().vx_batched_nms(boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), det.data_ptr(),
+                                counts.data_ptr() if counts is not None else None, B, K, D, int(n_classes),
+                                float(iou_threshold), tk, keep_idx.data_ptr(), out_det.data_ptr(),
+                                keep_counts.data_ptr(), out_cap, status.data_ptr(), ws.data_ptr(), nb,
+                                L.stream_ptr(dev))
+    L.check(rc, "vx_batched_nms")
+    return keep_idx, out_det, keep_counts, status
+
+
+def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_k: Optional[int] = None):
+    """decoder output -> NMS, sharing the meta words so one D2H copy reads counts, keep_counts, status."""
+    return batched_nms(c.boxes, c.scores, c.cls, c.det, c.counts, iou_threshold, n_classes, top_k, meta=c.meta)
+
+
+def raise_on_status(status: int):
+    """Map device status bits to the reference's exceptions."""
+    if status & L.VX_STATUS_NAN:
+        # reference: networks/modules/postprocess/yolov3.py:35-36
+        raise ValueError("your predictions have nan! please check")
+    if status & L.VX_STATUS_BAD_CLASS:
+        raise L.VortexHipError("class index outside [0, %d): not supported by libvortex_hip" % L.VX_MAX_CLASSES)

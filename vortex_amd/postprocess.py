@@ -1,0 +1,237 @@
+"""Drop-in for the reference's development-side post-process modules:
+  networks/modules/postprocess/yolov3.py        YoloV3Decoder :20-68, YoloV3PostProcess :71-79, get_postprocess :82-85
+  networks/modules/postprocess/utils/nms.py     NoNMS :8-28, NMS :31-54, batched_nms :57-98, BatchedNMS :100-123
+  networks/modules/postprocess/base_postprocess.py  BasicNMSPostProcess :18-125, BatchedNMSPostProcess :127-138,
+                                                    NoOpPostProcess :153-158
+Same class names, constructor arguments, forward signatures/annotations, `additional_inputs`,
+exception types and messages.  All arithmetic runs in libvortex_hip.so; the batched post-process
+handles every image of the batch in one set of launches and reads the per-image counts back with a
+single D2H copy (the reference loops per image in Python).
+
+Build-side extensions (default off == reference behaviour): `top_k`, and YoloV3FusedPostProcess which
+takes the three raw head tensors and never materialises the decoded [B,R,5+C] tensor."""
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _f(x) -> float:
+    """Tensor[1] / 0-dim tensor / python number -> python float (torchvision's `float` argument)."""
+    if isinstance(x, torch.Tensor):
+        return float(x.reshape(-1)[0].item())
+    return float(x)
+
+
+class YoloV3Decoder(nn.Module):
+    def __init__(self, img_size, threshold: bool = True):
+        super(YoloV3Decoder, self).__init__()
+        self.threshold = threshold
+        self.img_size = img_size
+
+    def decode_batch(self, input: torch.Tensor, score_threshold) -> ops.Candidates:
+        """All images in one launch, no host sync (used by BatchedNMSPostProcess)."""
+        if not (len(input.size()) == 3):
+            raise RuntimeError(
+                "this routine expects predictions is a 3-dimensional tensor! got %s dimension" % len(input.size()))
+        return ops.yolo_decode(input, float(self.img_size), _f(score_threshold), self.threshold)
+
+    def forward(self, input: torch.Tensor, score_threshold: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        if not (len(input.size()) == 3):
+            raise RuntimeError(
+                "this routine expects predictions is a 3-dimensional tensor! got %s dimension" % len(input.size()))
+        if input.size(0) != 1:
+            raise RuntimeError("current version only support single batch")
+        c = self.decode_batch(input, score_threshold)
+        meta = c.meta.cpu()
+        ops.raise_on_status(int(meta[-1]))
+        k = int(meta[0])
+        return c.boxes[0, :k], c.scores[0, :k], c.cls[0, :k], c.det[:, :k]
+
+
+class NoNMS:
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, detections: torch.Tensor, class_indexes: torch.Tensor, bboxes: torch.Tensor, scores: torch.Tensor, iou_threshold: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        _check_ranks(None, scores, bboxes, detections)
+        return detections, bboxes, scores, class_indexes
+
+
+def _check_ranks(class_indexes, scores, bboxes, detections):
+    if class_indexes is not None and not len(class_indexes.shape) == 1:
+        raise RuntimeError("expects `class_indices` to be 1-dimensional tensor, got %s with shape of %s" %
+                           (len(class_indexes.shape), class_indexes.shape))
+    if not len(scores.shape) == 1:
+        raise RuntimeError(
+            "expects `scores` to be 1-dimensional tensor, got %s with shape of %s" % (len(scores.shape), scores.shape))
+    if not len(bboxes.shape) == 2:
+        raise RuntimeError(
+            "expects `bboxes` to be 2-dimensional tensor, got %s with shape of %s" % (len(bboxes.shape), bboxes.shape))
+    if not len(detections.shape) == 3:
+        raise RuntimeError("expects `detections` to be 3-dimensional tensor, got %s with shape of %s" %
+                           (len(detections.shape), detections.shape))
+    if detections.size()[0] > 1:
+        raise RuntimeError("current version only support single batch")
+
+
+def _nms_single(boxes, scores, idxs, det, iou_threshold, top_k=None):
+    """One image through vx_batched_nms; returns (keep i64[K'], gathered det f32[1,K',D] or None)."""
+    K = int(boxes.shape[0])
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device), None
+    if det is None:
+        det = boxes.new_zeros((K, 1))
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.reshape(1, K, 4).float(), scores.reshape(1, K).float(), idxs.reshape(1, K).to(torch.int64),
+        det.reshape(1, K, -1).float(), None, _f(iou_threshold), 0, top_k)
+    meta = torch.cat((keep_counts, status)).cpu()
+    ops.raise_on_status(int(meta[1]))
+    n = int(meta[0])
+    return keep_idx[0, :n], out_det[:, :n]
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    # type: (torch.Tensor, torch.Tensor, torch.Tensor, float) -> torch.Tensor
+    """Class-aware NMS (reference utils/nms.py:57-98): int64 keep indices in decreasing score order."""
+    return _nms_single(boxes, scores, idxs, None, iou_threshold)[0]
+
+
+def nms(boxes, scores, iou_threshold):
+    """Class-agnostic greedy NMS (what the reference gets from torchvision.ops.nms)."""
+    idxs = torch.zeros(scores.shape, dtype=torch.int64, device=scores.device)
+    return _nms_single(boxes, scores, idxs, None, iou_threshold)[0]
+
+
+class NMS(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super(NMS, self).__init__()
+
+    def forward(self, detections: torch.Tensor, bboxes: torch.Tensor, scores: torch.Tensor, iou_threshold: torch.Tensor) -> torch.Tensor:
+        _check_ranks(None, scores, bboxes, detections)
+        if bboxes.numel() == 0:
+            return detections[:, :0]
+        idxs = torch.zeros(scores.shape, dtype=torch.int64, device=scores.device)
+        return _nms_single(bboxes, scores, idxs, detections[0], iou_threshold)[1]
+
+
+class BatchedNMS(nn.Module):
+    def __init__(self, *args, top_k: Optional[int] = None, **kwargs):
+        super(BatchedNMS, self).__init__()
+        self.nms_fn = batched_nms
+        self.top_k = top_k
+
+    def forward(self, detections: torch.Tensor, class_indexes: torch.Tensor, bboxes: torch.Tensor, scores: torch.Tensor, iou_threshold: torch.Tensor) -> torch.Tensor:
+        _check_ranks(class_indexes, scores, bboxes, detections)
+        if bboxes.numel() == 0:
+            return detections[:, :0]
+        return _nms_single(bboxes, scores, class_indexes, detections[0], iou_threshold, self.top_k)[1]
+
+
+class BasicNMSPostProcess(nn.Module):
+    """decoder -> nms composition (base_postprocess.py:18-125)."""
+
+    def __init__(self, decoder: Callable, nms: bool = True, top_k: Optional[int] = None):
+        super(BasicNMSPostProcess, self).__init__()
+        self.decoder = decoder
+        self.nms = BatchedNMS(top_k=top_k) if nms else NoNMS()
+        self.top_k = top_k
+        self.additional_inputs = (
+            ('score_threshold', (1,)),
+            ('iou_threshold', (1,)),
+        )
+
+    def _forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor) -> torch.Tensor:
+        bboxes, scores, class_indexes, detections = self.decoder(input=input, score_threshold=score_threshold)
+        return self.nms(detections=detections, bboxes=bboxes, scores=scores,
+                        class_indexes=class_indexes, iou_threshold=iou_threshold)
+
+    def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor) -> torch.Tensor:
+        return self._forward(input, score_threshold, iou_threshold)
+
+
+class BatchedNMSPostProcess(BasicNMSPostProcess):
+    """base_postprocess.py:127-138.  When the decoder offers `decode_batch` (ours do) and nms is
+    BatchedNMS, the whole batch runs as one sequence of launches; otherwise the reference's per-image
+    composition of the given callables is used."""
+
+    def __init__(self, decoder: Callable, nms: bool = True, top_k: Optional[int] = None):
+        super(BatchedNMSPostProcess, self).__init__(decoder, nms, top_k)
+
+    def n_classes_hint(self, input) -> int:
+        return 0
+
+    def forward_device(self, input, score_threshold, iou_threshold):
+        """No host sync: returns (out_det f32[B,cap,D], meta i32[2B+1] = counts|keep_counts|status)."""
+        c = self.decoder.decode_batch(input, score_threshold)
+        _, out_det, _, _ = ops.candidates_nms(c, _f(iou_threshold), self.n_classes_hint(input), self.top_k)
+        return out_det, c.meta
+
+    def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
+        if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
+            out_det, meta = self.forward_device(input, score_threshold, iou_threshold)
+            return finish_results(out_det, meta)
+        n_batch = input.size(0)
+        results = []
+        for i in range(n_batch):
+            results.append(self._forward(input[i].unsqueeze(0), score_threshold, iou_threshold).squeeze(0))
+        return tuple(results)
+
+
+def finish_results(out_det: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+    """The single D2H copy of the path: per-image keep counts + status -> tuple of f32[K'_i, D]."""
+    B = out_det.size(0)
+    m = meta.cpu()
+    ops.raise_on_status(int(m[-1]))
+    kc = m[B:2 * B].tolist()
+    return tuple(out_det[b, :kc[b]] for b in range(B))
+
+
+class YoloV3PostProcess(BatchedNMSPostProcess):
+    """Post-Process for yolo (postprocess/yolov3.py:71-79)."""
+
+    def __init__(self, img_size, threshold: bool = True, *args, **kwargs):
+        super(YoloV3PostProcess, self).__init__(
+            decoder=YoloV3Decoder(img_size=img_size, threshold=threshold), *args, **kwargs)
+
+    def n_classes_hint(self, input) -> int:
+        return int(input.size(-1)) - 5
+
+
+class _FusedYoloDecoder(nn.Module):
+    def __init__(self, img_size, threshold=True, anchors=ops.COCO_ANCHORS):
+        super().__init__()
+        self.img_size, self.threshold, self.anchors = img_size, threshold, anchors
+
+    def decode_batch(self, input: Sequence[torch.Tensor], score_threshold) -> ops.Candidates:
+        return ops.yolo_fused_decode(input, int(self.img_size), _f(score_threshold), self.threshold, self.anchors)
+
+
+class YoloV3FusedPostProcess(BatchedNMSPostProcess):
+    """Build-side extension: YoloV3Layer x3 + concat + YoloV3Decoder + BatchedNMS from the three RAW head
+    tensors (coarse -> fine: G = S/32, S/16, S/8), bit-identical to YoloV3Layer -> YoloV3PostProcess."""
+
+    def __init__(self, img_size, threshold: bool = True, anchors=ops.COCO_ANCHORS, top_k: Optional[int] = None):
+        super().__init__(decoder=_FusedYoloDecoder(img_size, threshold, anchors), nms=True, top_k=top_k)
+
+    def n_classes_hint(self, input) -> int:
+        return int(input[0].size(1)) // 3 - 5
+
+    def forward(self, input: Sequence[torch.Tensor], score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
+        out_det, meta = self.forward_device(input, score_threshold, iou_threshold)
+        return finish_results(out_det, meta)
+
+
+class NoOpPostProcess(nn.Module):
+    def __init__(self):
+        super(NoOpPostProcess, self).__init__()
+
+    def forward(self, input, *args, **kwargs):
+        return input
+
+
+def get_postprocess(*args, **kwargs):
+    """return postprocess method for yolo (postprocess/yolov3.py:82-85)"""
+    return YoloV3PostProcess(*args, **kwargs)
