@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — images/s of the detection pre-process + decode + NMS path on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+    K1  uint8 NHWC images  -> fp32 NCHW (normalise)                      vx_preprocess_u8hwc_f32nchw
+    K23 three raw YOLOv3 head tensors -> thresholded candidates          vx_yolo_fused_decode
+    NMS class-aware batched NMS -> per-image detection lists             vx_batched_nms + vx_pack_rows
+    + the API's single D2H read of the per-image counts and the tuple of per-image tensors.
+Workload: BASELINE.json configs[3] — YOLOv3 416x416, 80 classes, batch 256 per GPU (weak scaling:
+every rank processes its own 256-image shard; no data-path collective unless --allgather).
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+For N>1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+S, C = 416, 80
+R = 10647
+ROW_BYTES = (5 + C) * 4
+ALGO_BYTES_PRE = 3 * S * S + 12 * S * S                 # 2 595 840 B / image   
+ALGO_BYTES_DECODE = R * ROW_BYTES                       # 3 619 980 B / image   (+52 B per survivor)
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synth_on_device(B, dev, seed):
+    """Same distributions as oracle.synth_yolo_heads / synth_images, generated on the GPU."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8, device=dev)
+    heads = []
+    for G in (S // 32, S // 16, S // 8):
+        t = torch.randn(B, 3, 5 + C, G, G, generator=g, device=dev)
+        t[:, :, 2:4] *= 0.5
+        t[:, :, 4] = t[:, :, 4] * 2 - 4
+        t[:, :, 5:] = t[:, :, 5:] * 1.5 - 2
+        heads.append(t.view(B, 3 * (5 + C), G, G).contiguous())
+    return img, heads
+
+
+def cpu_baseline(sthr, ithr, budget_s=15.0, n_img=8):
+    """The oracle (CPU port of the reference path: torch-CPU ops one for one, per-image Python loop,
+    single-thread C greedy NMS) timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import vortex_oracle as O
+    img = O.synth_images(n_img, S, seed=0)
+    heads = O.synth_yolo_heads(n_img, S, C, seed=0)
+    st, it = torch.tensor([sthr]), torch.tensor([ithr])
+
+    def run():
+        x = O.normalize(img, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+        pred = O.yolo_head_eval(heads, S)
+        return x, O.yolo_postprocess(pred, st, it, S)
+
+    run()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        run()
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * n_img / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d iterations x %d images of the same YOLOv3-416/80-class synthetic workload, "
+                      "normalize + head decode + decoder + NMS, score_thr=%g iou_thr=%g" % (n, n_img, sthr, ithr)}
+
+
+def load_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate runs,
+    profiles/traffic_*.json; corrected as MI355X_MICROARCH.md §HBM prescribes).  None if not measured."""
+    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        return d.get(tag, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--score-thr", type=float, default=0.9)    # experiments/configs/yolov3_darknet_608.yml:57-58
+    ap.add_argument("--iou-thr", type=float, default=0.2)
+    ap.add_argument("--dense", action="store_true", help="score_thr 0.06 (tests/config/test_detection.yml:85-86)")
+    ap.add_argument("--unfused", action="store_true", help="API-boundary pipeline: YoloV3Layer x3 -> YoloV3PostProcess")
+    ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the detection lists every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+    if args.dense:
+        args.score_thr = 0.06
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import vortex_amd as V
+    from vortex_amd import _lib as L, ops, parallel
+
+    B = args.batch
+    img, heads = synth_on_device(B, dev, seed=1234 + rank)
+    norm = V.Normalize().to(dev)
+    sthr, ithr = torch.tensor([args.score_thr]), torch.tensor([args.iou_thr])
+    if args.unfused:
+        layers = []
+        off = 0
+        for h, mask in zip(heads, ((6, 7, 8), (3, 4, 5), (0, 1, 2))):
+            G = h.shape[-1]
+            layers.append((V.YoloV3Layer(S, (G, G), list(mask), ops.COCO_ANCHORS, C).to(dev).eval(), off))
+            off += 3 * G * G
+        post = V.YoloV3PostProcess(img_size=S)
+        decoded = torch.empty((B, R, 5 + C), device=dev)
+    else:
+        post = V.YoloV3FusedPostProcess(img_size=S)
+
+    def step():
+        x = norm(img)                                       # K1 (consumed by the backbone, out of scope)
+        if args.unfused:
+            for (layer, off), h in zip(layers, heads):
+                layer(h, out=decoded, row_offset=off)
+            packed, meta = post.forward_device(decoded, sthr, ithr)
+        else:
+            packed, meta = post.forward_device(heads, sthr, ithr)
+        if args.allgather:
+            return x, parallel.allgather_detections(packed, meta, B)
+        return x, V.postprocess.finish_results(packed, meta)   # the path's one D2H sync + tuple
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    n_det = sum(int(r.shape[0]) for r in out[1]) if not args.allgather else None
+
+    profile = not args.no_profile
+    if profile:
+        L.profile_enable(max(args.steps * 4, 16))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = L.profile_read() if profile else {}
+    if profile:
+        L.profile_disable()
+
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        n_gpus = world
+        ips = n_gpus * B * args.steps / dt
+        meta = out[1] if args.allgather else None
+        cand = int(ops.yolo_fused_decode(heads, S, args.score_thr).counts.sum().item())
+        dom = "vx_k_yolo_decode_rows" if args.unfused else "vx_k_yolo_fused"
+        roof = None
+        if dom in kern:
+            avg_ms = kern[dom]["avg_ms"]
+            algo = B * ALGO_BYTES_DECODE + 32 * cand
+            ach = algo / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(avg_ms, 5),
+                    "algorithmic_bytes_per_launch": algo,
+                    "traffic": load_traffic("unfused" if args.unfused else ("dense" if args.dense else "default"))}
+        pipe_bytes = B * ((ALGO_BYTES_PRE + ALGO_BYTES_DECODE) if not args.unfused
+                          else (ALGO_BYTES_PRE + 3 * ALGO_BYTES_DECODE))
+        result = {
+            "metric": "post/pre-process images/sec (decode+NMS)", "value": round(ips, 1), "unit": "images/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "YOLOv3 416x416 80 classes, batch %d per GPU, synthetic raw heads + uint8 images; "
+                                   "pre-process + %s decode + class-aware NMS; score_thr=%g iou_thr=%g%s"
+                                   % (B, "unfused (API-boundary)" if args.unfused else "fused head", args.score_thr,
+                                      args.iou_thr, "; RCCL all-gather of detections" if args.allgather else ""),
+                       "global_batch": B * n_gpus, "img_size": S, "classes": C, "rows_per_image": R,
+                       "candidates_per_batch": cand, "detections_per_batch": n_det,
+                       "parallelism": "dp%d (batch-sharded, no data-path collective%s)"
+                                      % (n_gpus, "; all-gather of results" if args.allgather else "")},
+            "pipeline_hbm": {"algorithmic_bytes_per_step": pipe_bytes,
+                             "achieved_GBps_per_gpu": round(pipe_bytes * args.steps / dt / 1e9, 1),
+                             "frac_of_8TBps": round(pipe_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
+        }
+        if roof is not None:
+            result["roofline"] = roof
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.score_thr, args.iou_thr)
+            result["cpu_baseline"] = cb
+            result["speedup_vs_cpu_port"] = round(ips / cb["value"], 1)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,23 @@ int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d
                    int out_capacity, int32_t *d_status,
                    void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------- tuple packing
+ * The `tuple(results)` of BatchedNMSPostProcess.forward (base_postprocess.py:131-138) as one launch:
+ * rows [0, min(d_counts[b],capacity)) of d_src f32[B,capacity,D] are copied back to back into d_dst
+ * (image order), *d_total (optional) = number of rows written.  d_dst holds >= B*capacity*D floats. */
+int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D,
+                 float *d_dst, int32_t *d_total, void *stream);
+
+/* ---------------------------------------------------------------- measurement hooks (no reference
+ * counterpart; bench.py's roofline leg).  When enabled, every kernel family launched by this library is
+ * bracketed by HIP events recorded on the launch stream (events are created here, once, outside the
+ * data path); vx_profile_get synchronises on them and returns the summed / min / max kernel time of
+ * the launches recorded since the last vx_profile_enable.  Process-global, not thread-safe. */
+int vx_profile_enable(int max_launches_per_kernel);
+int vx_profile_disable(void);
+int vx_profile_slots(void);
+int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, float *min_ms, float *max_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,12 @@ _SIGNATURES = {
     "vx_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vx_profile_enable": (c_int, [c_int]),
+    "vx_profile_disable": (c_int, []),
+    "vx_profile_slots": (c_int, []),
+    "vx_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_int),
+                               ctypes.POINTER(c_float), ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -103,3 +109,25 @@ def f6(v):
 
 def f18(v):
     return _F18(*[float(x) for x in v])
+
+
+def profile_enable(max_launches: int = 4096):
+    check(lib().vx_profile_enable(int(max_launches)), "vx_profile_enable")
+
+
+def profile_disable():
+    check(lib().vx_profile_disable(), "vx_profile_disable")
+
+
+def profile_read():
+    """{kernel family: dict(launches, total_ms, avg_ms, min_ms, max_ms)} for families launched since enable."""
+    out = {}
+    for i in range(lib().vx_profile_slots()):
+        name, n = ctypes.c_char_p(), c_int()
+        tot, mn, mx = c_float(), c_float(), c_float()
+        check(lib().vx_profile_get(i, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tot), ctypes.byref(mn),
+                                   ctypes.byref(mx)), "vx_profile_get")
+        if n.value:
+            out[name.value.decode()] = dict(launches=n.value, total_ms=tot.value, avg_ms=tot.value / n.value,
+                                            min_ms=mn.value, max_ms=mx.value)
+    return out

@@ -14,3 +14,76 @@ extern "C" const char *vx_error_string(int code) {
         default: return "unknown libvortex_hip error code";
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Profiling hooks (see vx_profile.h / include/vortex_hip.h).
+#include "vx_profile.h"
+#include <vector>
+
+bool vx_prof_on = false;
+
+namespace {
+struct Slot {
+    std::vector<hipEvent_t> ev;      // 2 events per launch
+    int launches = 0;
+    int cap = 0;
+};
+Slot g_slots[VX_PROF_NSLOTS];
+const char *g_names[VX_PROF_NSLOTS] = {
+    "vx_k_normalize/resize", "vx_k_yolo_head_decode", "vx_k_yolo_decode_rows", "vx_k_yolo_fused",
+    "vx_k_cand_finish", "vx_k_prior_decode", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather",
+    "vx_k_nms_sweep", "vx_k_sort(keys2)+output", "vx_k_pack_rows"};
+}  // namespace
+
+void vx_prof_begin_impl(int slot, hipStream_t st) {
+    Slot &s = g_slots[slot];
+    if (s.launches >= s.cap) return;
+    (void)hipEventRecord(s.ev[2 * s.launches], st);
+}
+void vx_prof_end_impl(int slot, hipStream_t st) {
+    Slot &s = g_slots[slot];
+    if (s.launches >= s.cap) return;
+    (void)hipEventRecord(s.ev[2 * s.launches + 1], st);
+    ++s.launches;
+}
+
+extern "C" int vx_profile_enable(int max_launches_per_kernel) {
+    if (max_launches_per_kernel <= 0 || max_launches_per_kernel > 65536) return VX_ERR_INVALID_ARG;
+    for (int i = 0; i < VX_PROF_NSLOTS; ++i) {
+        Slot &s = g_slots[i];
+        while ((int)s.ev.size() < 2 * max_launches_per_kernel) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return VX_ERR_LAUNCH;
+            s.ev.push_back(e);
+        }
+        s.cap = max_launches_per_kernel;
+        s.launches = 0;
+    }
+    vx_prof_on = true;
+    return VX_OK;
+}
+
+extern "C" int vx_profile_disable(void) {
+    vx_prof_on = false;
+    return VX_OK;
+}
+
+extern "C" int vx_profile_slots(void) { return VX_PROF_NSLOTS; }
+
+extern "C" int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, float *min_ms,
+                              float *max_ms) {
+    if (slot < 0 || slot >= VX_PROF_NSLOTS || !name || !launches || !total_ms || !min_ms || !max_ms)
+        return VX_ERR_INVALID_ARG;
+    Slot &s = g_slots[slot];
+    *name = g_names[slot];
+    *launches = s.launches;
+    float tot = 0.f, mn = 1e30f, mx = 0.f;
+    for (int i = 0; i < s.launches; ++i) {
+        if (hipEventSynchronize(s.ev[2 * i + 1]) != hipSuccess) return VX_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev[2 * i], s.ev[2 * i + 1]) != hipSuccess) return VX_ERR_LAUNCH;
+        tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx;
+    }
+    *total_ms = tot; *min_ms = s.launches ? mn : 0.f; *max_ms = mx;
+    return VX_OK;
+}

@@ -18,6 +18,7 @@
 // different classes are disjoint after the 2049*cls offset (|coordinate| < 1024) and a zero
 // intersection never exceeds an iou_threshold >= 0.
 #include "vx_common.h"
+#include "vx_profile.h"
 
 #define VX_SORT_CHMAX 16384
 #define VX_SWEEP_WT 4                 // wave routine: segments up to 64*WT boxes
@@ -450,20 +451,63 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     p.B = B; p.cap = capacity; p.npad_cap = npad_cap; p.D = D; p.n_classes = n_classes; p.top_k = top_k;
     p.out_cap = out_capacity; p.thr = iou_threshold;
 
+    vx_prof_begin(VX_PROF_NMS_KEYS, st);
     hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
                        (const long long *)d_cls, d_counts, p, w.keys1, w.count2, d_status);
+    vx_prof_end(VX_PROF_NMS_KEYS, st);
     vx_epi_params ep = {};
     ep.boxes = d_boxes; ep.sbox = w.sbox; ep.sarea = w.sarea; ep.cap = capacity;
     ep.det = d_det; ep.keep_idx = (long long *)d_keep_idx; ep.out_det = d_out_det; ep.keep_counts = d_keep_counts;
     ep.D = D; ep.top_k = top_k; ep.out_cap = out_capacity;
+    vx_prof_begin(VX_PROF_SORT1, st);
     int rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
+    vx_prof_end(VX_PROF_SORT1, st);
     if (rc != VX_OK) return rc;
     int X = (n_classes + 7) / 8;          // 2 class groups of 4 waves per workgroup ...
     if (X > 32) X = 32;                   // ... capped: 4096 classes / 32 = 128 = VX_SWEEP_MAXBIG
     if (X < 1) X = 1;
+    vx_prof_begin(VX_PROF_SWEEP, st);
     hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(256), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
                        w.count2);
+    vx_prof_end(VX_PROF_SWEEP, st);
+    vx_prof_begin(VX_PROF_SORT2, st);
     rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
+    vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tuple packing (the `tuple(results)` of base_postprocess.py:131-138 without B Python slices):
+// rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
+__global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ src, const int *__restrict__ counts,
+                                                      int B, int cap, int D, float *__restrict__ dst,
+                                                      int *__restrict__ total) {
+    __shared__ int s_part[256];
+    const int b = blockIdx.x;
+    int acc = 0;
+    for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const long long off = s_part[0];
+    const int n = min(counts[b], cap);
+    if (b == B - 1 && threadIdx.x == 0 && total) *total = (int)off + n;
+    const float *s = src + (long long)b * cap * D;
+    float *d = dst + off * D;
+    for (int i = threadIdx.x; i < n * D; i += 256) d[i] = s[i];
+}
+
+extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D, float *d_dst,
+                            int32_t *d_total, void *stream) {
+    if (!d_src || !d_counts || !d_dst) return VX_ERR_INVALID_ARG;
+    if (B <= 0 || capacity <= 0 || D <= 0) return VX_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    vx_prof_begin(VX_PROF_PACK, st);
+    hipLaunchKernelGGL(vx_k_pack_rows, dim3(B), dim3(256), 0, st, d_src, d_counts, B, capacity, D, d_dst, d_total);
+    vx_prof_end(VX_PROF_PACK, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }

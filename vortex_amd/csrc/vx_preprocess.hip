@@ -9,6 +9,7 @@
 // builds that table once in LDS with the reference's exact IEEE operation order and the
 // streaming loop is a table lookup: bit-exact by construction, no per-pixel divisions.
 #include "vx_common.h"
+#include "vx_profile.h"
 
 struct vx_norm_params { float mean[3]; float std[3]; float scaler; int flip; };
 
@@ -160,6 +161,7 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
     p.scaler = (float)scaler;
     p.flip = flip ? 1 : 0;
     const int max_blocks = 256 * 8;
+    vx_prof_begin(VX_PROF_PREPROCESS, st);
     if (Hs == Hd && Ws == Wd) {
         long long HW = (long long)Hs * Ws;
         bool vec = (HW % 4 == 0) && (((uintptr_t)d_src & 3) == 0) && (((uintptr_t)d_dst & 15) == 0);
@@ -188,5 +190,6 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
         hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
                            d_src, d_dst, B, r, p);
     }
+    vx_prof_end(VX_PROF_PREPROCESS, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }

@@ -5,6 +5,7 @@
 // contract is the build-authored spec restated in oracle/vortex_oracle.py:prior_box_decode
 // (evidence: scripts/export_check/README.md:54-63, :107, :113).  Parity unpinned.
 #include "vx_common.h"
+#include "vx_profile.h"
 
 struct vx_prior_params {
     int B, P, L, NC, NCOL, NCP, tiles_per_img;
@@ -128,8 +129,10 @@ extern "C" int vx_prior_decode(const float *d_in, const float *d_priors, int B, 
     p.use_thr = use_threshold ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     size_t lds = (size_t)256 * p.NCP * sizeof(float);
+    vx_prof_begin(VX_PROF_PRIOR, st);
     hipLaunchKernelGGL(vx_k_prior_decode, dim3((unsigned)(B * tiles)), dim3(256), lds, st, d_in,
                        (const vx_f4 *)d_priors, stage, stage_lmk, tile_counts, d_status, p);
+    vx_prof_end(VX_PROF_PRIOR, st);
     vx_finish_params f;
     f.R = P; f.tiles_per_img = tiles; f.D = 6 + 2 * n_landmarks; f.L = n_landmarks; f.uniform_tile_rows = 256;
     int rc = vx_internal_cand_finish(stage, stage_lmk, tile_counts, B, f, d_boxes, d_scores, (long long *)d_cls, d_det,

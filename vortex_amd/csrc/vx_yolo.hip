@@ -8,6 +8,7 @@
 // Reference: networks/modules/heads/detection/yolov3.py:263-304 (YoloV3Layer eval),
 // networks/models/detection/yolov3.py:72-76 (concat), networks/modules/postprocess/yolov3.py:29-68.
 #include "vx_common.h"
+#include "vx_profile.h"
 
 // ------------------------------------------------------------------------------------------------
 // K2: one workgroup = 64 consecutive cells of one (image, anchor) plane, all 5+C channels.
@@ -112,8 +113,10 @@ extern "C" int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G
     size_t lds = (size_t)(64 * NP + 4) * sizeof(float);
     bool vec = (cells % 4 == 0) && (((uintptr_t)d_in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    vx_prof_begin(VX_PROF_HEAD_DECODE, st);
     if (vec) hipLaunchKernelGGL(vx_k_yolo_head_decode<true>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
     else     hipLaunchKernelGGL(vx_k_yolo_head_decode<false>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
+    vx_prof_end(VX_PROF_HEAD_DECODE, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
 
@@ -414,8 +417,10 @@ int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int
                             vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,
                             int *counts, hipStream_t st) {
     vx_fused_params fp = {};
+    vx_prof_begin(VX_PROF_FINISH, st);
     hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, (const vx_rec *)stage, stage_lmk, tile_counts, fp,
                        f, boxes, scores, cls, det, counts);
+    vx_prof_end(VX_PROF_FINISH, st);
     return VX_OK;
 }
 
@@ -456,13 +461,13 @@ extern "C" int vx_yolo_decode(const float *d_pred, int B, int R, int C, float im
     p.B = B; p.R = R; p.C = C; p.NP = NP; p.tiles_per_img = tiles;
     p.img_size = img_size; p.thr = score_threshold; p.use_thr = use_threshold ? 1 : 0;
     size_t lds = (size_t)(64 * NP + 4) * sizeof(float);
+    vx_prof_begin(VX_PROF_DECODE_ROWS, st);
     hipLaunchKernelGGL(vx_k_yolo_decode_rows, dim3((unsigned)(B * tiles)), dim3(256), lds, st, d_pred, stage,
                        tile_counts, d_status, p);
-    vx_fused_params fp = {};
+    vx_prof_end(VX_PROF_DECODE_ROWS, st);
     vx_finish_params f;
     f.R = R; f.tiles_per_img = tiles; f.D = 6; f.L = 0; f.uniform_tile_rows = 64;
-    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, fp, f,
-                       d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
+    vx_internal_cand_finish(stage, nullptr, tile_counts, B, f, d_boxes, d_scores, (long long *)d_cls, d_det, d_counts, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
 
@@ -548,10 +553,14 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     long long nblk = (waves + 3) / 4;
     if (nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    vx_prof_begin(VX_PROF_FUSED, st);
     hipLaunchKernelGGL(vx_k_yolo_fused, dim3((unsigned)nblk), dim3(256), 0, st, p, stage, tile_counts, d_status);
+    vx_prof_end(VX_PROF_FUSED, st);
     vx_finish_params f;
     f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;
+    vx_prof_begin(VX_PROF_FINISH, st);
     hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, p, f,
                        d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
+    vx_prof_end(VX_PROF_FINISH, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }

@@ -192,6 +192,16 @@ def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_
     return batched_nms(c.boxes, c.scores, c.cls, c.det, c.counts, iou_threshold, n_classes, top_k, meta=c.meta)
 
 
+def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor) -> torch.Tensor:
+    """f32[B,cap,D] + i32[B] -> f32[B*cap, D] with the kept rows of all images back to back."""
+    B, cap, D = out_det.shape
+    packed = torch.empty((B * cap, D), dtype=torch.float32, device=out_det.device)
+    rc = L.lib().vx_pack_rows(out_det.data_ptr(), keep_counts.data_ptr(), B, cap, D, packed.data_ptr(), None,
+                              L.stream_ptr(out_det.device))
+    L.check(rc, "vx_pack_rows")
+    return packed
+
+
 def raise_on_status(status: int):
     """Map device status bits to the reference's exceptions."""
     if status & L.VX_STATUS_NAN:

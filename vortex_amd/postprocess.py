@@ -164,10 +164,11 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         return 0
 
     def forward_device(self, input, score_threshold, iou_threshold):
-        """No host sync: returns (out_det f32[B,cap,D], meta i32[2B+1] = counts|keep_counts|status)."""
+        """No host sync: returns (packed f32[B*cap,D] = kept rows of all images back to back,
+        meta i32[2B+1] = counts|keep_counts|status)."""
         c = self.decoder.decode_batch(input, score_threshold)
-        _, out_det, _, _ = ops.candidates_nms(c, _f(iou_threshold), self.n_classes_hint(input), self.top_k)
-        return out_det, c.meta
+        _, out_det, keep_counts, _ = ops.candidates_nms(c, _f(iou_threshold), self.n_classes_hint(input), self.top_k)
+        return ops.pack_rows(out_det, keep_counts), c.meta
 
     def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
@@ -180,13 +181,14 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         return tuple(results)
 
 
-def finish_results(out_det: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tensor, ...]:
-    """The single D2H copy of the path: per-image keep counts + status -> tuple of f32[K'_i, D]."""
-    B = out_det.size(0)
+def finish_results(packed: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+    """The single D2H copy of the path: per-image keep counts + status -> tuple of f32[K'_i, D]
+    (views of the packed buffer, one split call instead of B Python slices)."""
+    B = (meta.numel() - 1) // 2
     m = meta.cpu()
     ops.raise_on_status(int(m[-1]))
     kc = m[B:2 * B].tolist()
-    return tuple(out_det[b, :kc[b]] for b in range(B))
+    return tuple(torch.split(packed[:sum(kc)], kc))
 
 
 class YoloV3PostProcess(BatchedNMSPostProcess):
