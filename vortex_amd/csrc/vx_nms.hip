@@ -65,9 +65,92 @@ struct vx_epi_params {
     const float *det; long long *keep_idx; float *out_det; int *keep_counts; int D, top_k, out_cap;
 };
 
-__device__ __forceinline__ void vx_cmpx(u64 &a, u64 &b, bool asc) {
-    bool sw = asc ? (a > b) : (a < b);
-    if (sw) { u64 t = a; a = b; b = t; }
+__device__ __forceinline__ u64 vx_shfl_xor_u64(u64 v, int j) {
+    unsigned lo = __shfl_xor((unsigned)v, j), hi = __shfl_xor((unsigned)(v >> 32), j);
+    return ((u64)hi << 32) | lo;
+}
+
+#define VX_SORT_E 4                            // keys per lane in the register pass
+#define VX_SORT_BLK (64 * VX_SORT_E)           // keys per wave in the register pass
+
+// Stages k_from..k_to of the network restricted to partner distances j < VX_SORT_BLK: every wave
+// keeps a block of 256 consecutive keys in registers (lane l holds keys l, l+64, l+128, l+192).
+// Distances 128 and 64 pair two registers of the same lane, distances <= 32 exchange with lane^j
+// (ds_bpermute) — no LDS storage traffic between steps, no barrier until the end, and the four
+// chains of a lane are independent (their cross-lane latencies overlap).  Keys e >= m (only when
+// m < 256) behave as sentinels.
+__device__ __forceinline__ void vx_bitonic_regs(u64 *sk, int m, int base, int k_from, int k_to) {
+    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nblk = (m + VX_SORT_BLK - 1) / VX_SORT_BLK;
+    const int rmax = min(VX_SORT_E, (m + 63) >> 6);
+    for (int blk = wave; blk < nblk; blk += nw) {
+        const int e0 = blk * VX_SORT_BLK + lane;
+        u64 v[VX_SORT_E];
+#pragma unroll
+        for (int r = 0; r < VX_SORT_E; ++r) v[r] = (e0 + r * 64 < m) ? sk[e0 + r * 64] : VX_KEY_SENTINEL;
+        for (int k = k_from; k <= k_to; k <<= 1) {
+            // register-register steps (j = 128, 64)
+#pragma unroll
+            for (int rr = VX_SORT_E / 2; rr >= 1; rr >>= 1) {
+                if (rr * 64 <= (k >> 1)) {
+#pragma unroll
+                    for (int r = 0; r < VX_SORT_E; ++r) {
+                        if ((r & rr) == 0 && (r | rr) < rmax) {
+                            bool asc = ((base + e0 + r * 64) & k) == 0;
+                            u64 a = v[r], c = v[r | rr];
+                            bool sw = asc ? (a > c) : (a < c);
+                            v[r] = sw ? c : a;
+                            v[r | rr] = sw ? a : c;
+                        }
+                    }
+                }
+            }
+            // cross-lane steps (j = 32 .. 1)
+            for (int j = min(k >> 1, 32); j > 0; j >>= 1) {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int r = 0; r < VX_SORT_E; ++r) {
+                    if (r < rmax) {
+                        bool asc = ((base + e0 + r * 64) & k) == 0;
+                        u64 o = vx_shfl_xor_u64(v[r], j);
+                        v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < VX_SORT_E; ++r)
+            if (e0 + r * 64 < m) sk[e0 + r * 64] = v[r];
+    }
+    __syncthreads();
+}
+
+// Stages k_lo..k_hi of the ascending bitonic network over the m (power of two) keys in LDS whose
+// global indices are base..base+m-1.  Partner distances >= 256 go through LDS (one barrier each),
+// the rest through vx_bitonic_regs; stages up to k = 256 need no LDS step at all.  Ends synchronised.
+__device__ __forceinline__ void vx_bitonic_sort_lds(u64 *sk, int m, int base, int k_lo, int k_hi) {
+    const int nt = blockDim.x, half = m >> 1;
+    int k = k_lo;
+    if (k <= VX_SORT_BLK) {
+        int kt = min(k_hi, VX_SORT_BLK);
+        vx_bitonic_regs(sk, m, base, k, kt);
+        k = kt << 1;
+    }
+    for (; k <= k_hi; k <<= 1) {
+        for (int j = min(k >> 1, half); j >= VX_SORT_BLK; j >>= 1) {
+#pragma unroll 2
+            for (int t = threadIdx.x; t < half; t += nt) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int q = i | j;
+                bool asc = ((base + i) & k) == 0;
+                u64 a = sk[i], c = sk[q];
+                bool sw = asc ? (a > c) : (a < c);
+                if (sw) { sk[i] = c; sk[q] = a; }
+            }
+            __syncthreads();
+        }
+        vx_bitonic_regs(sk, m, base, k, k);
+    }
 }
 
 __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, const int *__restrict__ counts,
@@ -88,23 +171,9 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
         for (int i = threadIdx.x; i < m; i += nt) sk[i] = g[i];
     }
     __syncthreads();
-    const int half = m >> 1;
     const int k_lo = sp.k_merge == 0 ? 2 : sp.k_merge;
     const int k_hi = sp.k_merge == 0 ? m : sp.k_merge;
-    for (int k = k_lo; k <= k_hi; k <<= 1) {
-        for (int j = min(k >> 1, half); j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += nt) {
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                int q = i | j;
-                bool asc = ((base + i) & k) == 0;
-                u64 a = sk[i], c = sk[q];
-                bool sw = asc ? (a > c) : (a < c);
-                if (sw) { sk[i] = c; sk[q] = a; }
-            }
-            __syncthreads();
-        }
-        if (k == 0x40000000) break;
-    }
+    vx_bitonic_sort_lds(sk, m, base, k_lo, k_hi);
     const bool final_stage = (sp.k_merge == 0) ? (npad <= sp.CH) : (sp.k_merge == npad);
     // keys go back to global (next stage / sweep read them)
     for (int i = threadIdx.x; i < m; i += nt) g[i] = sk[i];
@@ -207,6 +276,56 @@ __device__ __forceinline__ void vx_emit_kept(u64 m, bool mine, u64 key1, u64 *__
     if (vx_lane() == 0) base = atomicAdd(count2, __popcll(m));
     base = __builtin_amdgcn_readfirstlane(base);
     if (mine) keys2[base + vx_mbcnt(m)] = vx_key2_from_key1(key1);
+}
+
+// Pair-dense wave routine for a segment of n <= 64 boxes (the common per-class size): the
+// n(n-1)/2 pairs (i<j) are dealt 64 per step to the lanes, so a 20-box class costs 3 IoU steps
+// instead of 20.  Lane l keeps box l; a pair's two boxes arrive by cross-lane reads.  Every
+// "i suppresses j" sets bit j of row i of a 64x64 bit matrix in LDS (wmask, 64 words of this wave);
+// the greedy order is then resolved with scalar bit operations only.
+__device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
+                                               const u64 *keys1, int lo, int n, float thr, u64 *wmask,
+                                               u64 *__restrict__ keys2, int *count2) {
+    const int lane = vx_lane();
+    vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+    float ar = 0.f;
+    if (lane < n) { bx = sbox[lo + lane]; ar = sarea[lo + lane]; }
+    u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const int npairs = n * (n - 1) / 2;
+    if (npairs > 0) {
+        wmask[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        for (int p0 = 0; p0 < npairs; p0 += 64) {
+            const int p = p0 + lane;
+            const bool pv = p < npairs;
+            // p = j(j-1)/2 + i, 0 <= i < j
+            int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+            if (j * (j - 1) / 2 > p) --j;
+            if ((j + 1) * j / 2 <= p) ++j;
+            int i = p - j * (j - 1) / 2;
+            if (!pv) { i = 0; j = 0; }
+            float ix1 = __shfl(bx.x, i), iy1 = __shfl(bx.y, i), ix2 = __shfl(bx.z, i), iy2 = __shfl(bx.w, i);
+            float ia = __shfl(ar, i);
+            float jx1 = __shfl(bx.x, j), jy1 = __shfl(bx.y, j), jx2 = __shfl(bx.z, j), jy2 = __shfl(bx.w, j);
+            float ja = __shfl(ar, j);
+            bool sup = pv && vx_iou_gt(ix1, iy1, ix2, iy2, ia, jx1, jy1, jx2, jy2, ja, thr);
+            if (sup) atomicOr((unsigned long long *)&wmask[i], 1ull << j);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const u64 row = wmask[lane];
+        const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
+        u64 todo = alive;
+        while (todo) {
+            int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                     (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
+            alive &= ~mi;
+            todo = alive & ~((2ull << i) - 1ull);
+        }
+    }
+    const bool mine = (alive >> lane) & 1ull;
+    u64 key = mine ? keys1[lo + lane] : 0ull;
+    vx_emit_kept(alive, mine, key, keys2, count2);
 }
 
 // Wave routine: a segment of n <= 64*WT boxes, everything in registers.
@@ -374,9 +493,155 @@ __global__ __launch_bounds__(256) void vx_k_nms_sweep(const u64 *__restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole NMS of one image in ONE workgroup (capacity <= VX_SORT_CHMAX): keys are built and sorted in
+// LDS, the class-offset boxes gathered into sorted order, every class segment swept (one wave per
+// small segment, the whole workgroup per large one; segment bounds come from 64-ary searches of the
+// LDS-resident keys), the kept keys sorted back into score order in the same LDS and the outputs
+// written.  One launch for the batch instead of five; work scales with the image's own count.
+struct vx_image_args {
+    vx_nms_params p;
+    const float *boxes, *scores, *det;
+    const long long *cls;
+    const int *counts;
+    vx_f4 *sbox;
+    float *sarea;
+    u64 *keys2;
+    long long *keep_idx;
+    float *out_det;
+    int *keep_counts, *status;
+    int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
+    u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b (diagnostics, 8 stores per block)
+};
+
+__global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    __shared__ vx_sweep_smem S;
+    __shared__ int s_big[VX_SWEEP_MAXBIG][2];
+    __shared__ int s_nbig, s_count2, s_nseg;
+    __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
+    __shared__ u64 s_wmask[16][64];
+    const vx_nms_params &p = a.p;
+    const int b = blockIdx.x, nt = blockDim.x;
+    const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
+    if (n == 0) {
+        if (threadIdx.x == 0) a.keep_counts[b] = 0;
+        return;
+    }
+    const int npad = vx_next_pow2(n);
+    const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
+#define VX_STAMP(k) do { if (threadIdx.x == 0) a.stamps[b * 8 + (k)] = clock64(); } while (0)
+    VX_STAMP(0);
+    bool bad = false;
+    for (int i = threadIdx.x; i < npad; i += nt) {
+        u64 key = VX_KEY_SENTINEL;
+        if (i < n) {
+            long long c = a.cls[ib + i];
+            if (c < 0 || c >= VX_MAX_CLASSES) { bad = true; c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
+            key = vx_key1((int)c, a.scores[ib + i], i);
+        }
+        sk[i] = key;
+    }
+    if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
+    if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; }
+    __syncthreads();
+    VX_STAMP(1);
+    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    VX_STAMP(2);
+    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
+    vx_f4 *sb = a.sbox + ob;
+    float *sa = a.sarea + ob;
+    for (int i = threadIdx.x; i < n; i += nt) {
+        u64 key = sk[i];
+        float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
+        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
+        bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
+        sb[i] = bx;
+        sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
+    }
+    __syncthreads();
+    VX_STAMP(3);
+    u64 *k2 = a.keys2 + ob;
+    const int wave = threadIdx.x >> 6, nw = nt >> 6, lane = vx_lane();
+    // ordered list of class-segment starts: boundary flags -> per-64-group counts -> scan -> scatter
+    int *seg = a.seg + (long long)b * VX_MAX_CLASSES;
+    const int groups = (n + 63) >> 6;
+    for (int g = wave; g < groups; g += nw) {
+        int i = g * 64 + lane;
+        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
+        u64 m = __ballot(flag);
+        if (lane == 0) s_gcnt[g] = __popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int c[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; c[q] = g < groups ? s_gcnt[g] : 0; tot += c[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; if (g < groups) s_gcnt[g] = run; run += c[q]; }
+        if (lane == 63) s_nseg = incl;
+    }
+    __syncthreads();
+    for (int g = wave; g < groups; g += nw) {
+        int i = g * 64 + lane;
+        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
+        u64 m = __ballot(flag);
+        if (flag) seg[s_gcnt[g] + vx_mbcnt(m)] = i;
+    }
+    __syncthreads();
+    const int nseg = s_nseg;
+    for (int s = wave; s < nseg; s += nw) {
+        int lo = seg[s];
+        int hi = s + 1 < nseg ? seg[s + 1] : n;
+        int len = hi - lo;
+        if (len <= 64) {
+            vx_sweep_pairs(sb, sa, sk, lo, len, p.thr, s_wmask[wave], k2, &s_count2);
+        } else if (len <= 64 * VX_SWEEP_WT) {
+            vx_sweep_wave(sb, sa, sk, lo, len, p.thr, k2, &s_count2);
+        } else if (lane == 0) {
+            int q = atomicAdd(&s_nbig, 1);
+            if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; }
+        }
+    }
+    __syncthreads();
+    VX_STAMP(4);
+    const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], p.thr, k2, &s_count2);
+    __syncthreads();
+    VX_STAMP(5);
+    // kept keys back into global score order, then the outputs
+    const int n2 = s_count2;
+    const int npad2 = vx_next_pow2(max(n2, 1));
+    __syncthreads();                       // everyone has read s_count2 / finished with keys1 in sk
+    for (int i = threadIdx.x; i < npad2; i += nt) sk[i] = i < n2 ? k2[i] : VX_KEY_SENTINEL;
+    __syncthreads();
+    vx_bitonic_sort_lds(sk, npad2, 0, 2, npad2);
+    VX_STAMP(6);
+    int nk = n2;
+    if (p.top_k > 0) nk = min(nk, p.top_k);
+    nk = min(nk, p.out_cap);
+    if (threadIdx.x == 0) a.keep_counts[b] = nk;
+    const int D = p.D;
+    for (int i = threadIdx.x; i < nk; i += nt)
+        a.keep_idx[(long long)b * p.out_cap + i] = (long long)(sk[i] & 0xFFFFFFFFull);
+    // row gather: consecutive threads copy consecutive floats of the output
+    for (int e = threadIdx.x; e < nk * D; e += nt) {
+        int i = e / D, q = e - i * D;
+        int idx = (int)(sk[i] & 0xFFFFFFFFull);
+        a.out_det[((long long)b * p.out_cap + i) * D + q] = a.det[(ib + idx) * D + q];
+    }
+    __syncthreads();
+    VX_STAMP(7);
+#undef VX_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline size_t vx_align256n(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; size_t bytes; };
+struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; size_t bytes; };
 
 static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     vx_nms_ws w;
@@ -388,6 +653,8 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.sarea = (float *)(p + off); off += vx_align256n(n * sizeof(float));
     w.keys2 = (u64 *)(p + off); off += vx_align256n(n * sizeof(u64));
     w.count2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+    w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * 8 * sizeof(u64));   // per-image phase clocks (diagnostics)
+    w.seg = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
     w.bytes = off;
     return w;
 }
@@ -451,6 +718,29 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     p.B = B; p.cap = capacity; p.npad_cap = npad_cap; p.D = D; p.n_classes = n_classes; p.top_k = top_k;
     p.out_cap = out_capacity; p.thr = iou_threshold;
 
+    if (npad_cap <= VX_SORT_CHMAX) {
+        // single-launch path: one workgroup per image, keys stay in LDS
+        static bool image_attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
+        if (!image_attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *)vx_k_nms_image, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
+                return VX_ERR_LAUNCH;
+            image_attr_set[dev] = true;
+        }
+        vx_image_args a;
+        a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.det = d_det; a.cls = (const long long *)d_cls;
+        a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
+        a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
+        a.status = d_status; a.stamps = w.stamps; a.seg = w.seg;
+        int threads = npad_cap >= 1024 ? 1024 : 256;
+        vx_prof_begin(VX_PROF_NMS_IMAGE, st);
+        hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)npad_cap * sizeof(u64), st, a);
+        vx_prof_end(VX_PROF_NMS_IMAGE, st);
+        return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+    }
+
     vx_prof_begin(VX_PROF_NMS_KEYS, st);
     hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
                        (const long long *)d_cls, d_counts, p, w.keys1, w.count2, d_status);
@@ -510,4 +800,11 @@ extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, 
     hipLaunchKernelGGL(vx_k_pack_rows, dim3(B), dim3(256), 0, st, d_src, d_counts, B, capacity, D, d_dst, d_total);
     vx_prof_end(VX_PROF_PACK, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+// diagnostics: byte offset of the u64[B][8] phase-stamp block inside the NMS workspace
+extern "C" size_t vx_batched_nms_stamps_offset(int B, int capacity) {
+    if (B <= 0 || capacity <= 0 || capacity > VX_MAX_CANDIDATES) return 0;
+    vx_nms_ws w = vx_nms_carve(nullptr, B, vx_next_pow2(capacity));
+    return (size_t)((char *)w.stamps - (char *)nullptr);
 }

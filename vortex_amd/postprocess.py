@@ -170,6 +170,13 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         _, out_det, keep_counts, _ = ops.candidates_nms(c, _f(iou_threshold), self.n_classes_hint(input), self.top_k)
         return ops.pack_rows(out_det, keep_counts), c.meta
 
+    def forward_async(self, input, score_threshold, iou_threshold) -> "PendingDetections":
+        """Enqueue the whole post-process plus the D2H copy of the counts and return at once; the
+        caller overlaps the next batch's launches with this one's GPU work and calls .result() later
+        (serving loops).  forward() == forward_async().result()."""
+        packed, meta = self.forward_device(input, score_threshold, iou_threshold)
+        return PendingDetections(packed, meta)
+
     def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
             out_det, meta = self.forward_device(input, score_threshold, iou_threshold)
@@ -181,14 +188,33 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         return tuple(results)
 
 
+def _split_results(packed: torch.Tensor, m) -> Tuple[torch.Tensor, ...]:
+    B = (len(m) - 1) // 2
+    ops.raise_on_status(int(m[-1]))
+    kc = m[B:2 * B]
+    return tuple(torch.split(packed[:sum(kc)], kc))
+
+
 def finish_results(packed: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tensor, ...]:
     """The single D2H copy of the path: per-image keep counts + status -> tuple of f32[K'_i, D]
     (views of the packed buffer, one split call instead of B Python slices)."""
-    B = (meta.numel() - 1) // 2
-    m = meta.cpu()
-    ops.raise_on_status(int(m[-1]))
-    kc = m[B:2 * B].tolist()
-    return tuple(torch.split(packed[:sum(kc)], kc))
+    return _split_results(packed, meta.cpu().tolist())
+
+
+class PendingDetections:
+    """Result of forward_async: the counts travel to pinned host memory on the launch stream, an
+    event marks their arrival; result() waits for that event only (not for later launches)."""
+
+    def __init__(self, packed: torch.Tensor, meta: torch.Tensor):
+        self.packed = packed
+        self._host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
+        self._host.copy_(meta, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(meta.device))
+
+    def result(self) -> Tuple[torch.Tensor, ...]:
+        self._event.synchronize()
+        return _split_results(self.packed, self._host.tolist())
 
 
 class YoloV3PostProcess(BatchedNMSPostProcess):
