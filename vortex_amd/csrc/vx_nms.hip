@@ -230,17 +230,42 @@ __global__ __launch_bounds__(256) void vx_k_sort_global(u64 *__restrict__ keys, 
 
 // ------------------------------------------------------------------------------------------------
 // IoU test, operation for operation as oracle/nms_oracle.c (box i = the kept, higher-scoring one).
+//
+// The reference's predicate is  fl(inter / uni) > thr  with an IEEE division.  The division (12
+// instructions) is only executed when the cheap bracket  inter > fl(thr(1+2^-19))*uni  /
+// inter < fl(thr(1-2^-19))*uni  cannot decide: inside the bracket the true quotient is more than
+// 2^-20 relative (>= 4 ulp) away from thr, so the rounded quotient falls on the same side — the
+// result is bit-identical, the undecided band is hit by ~1 pair in 10^5.  max/min use v_max/v_min:
+// they differ from std::max/min only for NaN or signed-zero operands, which cannot change w, h.
+struct vx_thr { float thr, hi, lo; bool fast; };
+
+__device__ __forceinline__ vx_thr vx_make_thr(float thr) {
+    vx_thr t;
+    t.thr = thr;
+    t.hi = thr * (1.0f + 0x1p-19f);
+    t.lo = thr * (1.0f - 0x1p-19f);
+    t.fast = thr >= 1e-6f && thr <= 1e6f;      // keeps thr*uni a normal number for 1e-30 < uni < 1e30
+    return t;
+}
+
 __device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
-                                          float jx1, float jy1, float jx2, float jy2, float ja, float thr) {
-    float xx1 = ix1 < jx1 ? jx1 : ix1;
-    float yy1 = iy1 < jy1 ? jy1 : iy1;
-    float xx2 = jx2 < ix2 ? jx2 : ix2;
-    float yy2 = jy2 < iy2 ? jy2 : iy2;
-    float w = xx2 - xx1; w = 0.0f < w ? w : 0.0f;
-    float h = yy2 - yy1; h = 0.0f < h ? h : 0.0f;
+                                          float jx1, float jy1, float jx2, float jy2, float ja, const vx_thr &T) {
+    // v_med3_f32(a, b, +-inf) = max / min in one instruction, no canonicalising pre-ops
+    float xx1 = __builtin_amdgcn_fmed3f(ix1, jx1, INFINITY);
+    float yy1 = __builtin_amdgcn_fmed3f(iy1, jy1, INFINITY);
+    float xx2 = __builtin_amdgcn_fmed3f(ix2, jx2, -INFINITY);
+    float yy2 = __builtin_amdgcn_fmed3f(iy2, jy2, -INFINITY);
+    float w = __builtin_amdgcn_fmed3f(xx2 - xx1, 0.0f, INFINITY);
+    float h = __builtin_amdgcn_fmed3f(yy2 - yy1, 0.0f, INFINITY);
     float inter = w * h;
-    float ovr = inter / (ia + ja - inter);
-    return ovr > thr;
+    float uni = ia + ja - inter;
+    if (T.fast) {
+        bool hi = inter > T.hi * uni, lo = inter < T.lo * uni;
+        bool res = hi;
+        if (!((hi || lo) && uni > 1e-30f && uni < 1e30f)) res = (inter / uni) > T.thr;
+        return res;
+    }
+    return (inter / uni) > T.thr;
 }
 
 __device__ __forceinline__ float vx_bcast(float v, int lane_uniform) {
@@ -278,14 +303,27 @@ __device__ __forceinline__ void vx_emit_kept(u64 m, bool mine, u64 key1, u64 *__
     if (mine) keys2[base + vx_mbcnt(m)] = vx_key2_from_key1(key1);
 }
 
+// pair index p = j(j-1)/2 + i (0 <= i < j < 64)  ->  (j << 6) | i, for all 2016 pairs of a 64-box tile
+#define VX_NPAIRS64 2016
+__device__ __forceinline__ void vx_build_pair_lut(unsigned short *lut) {
+    for (int p = threadIdx.x; p < VX_NPAIRS64; p += blockDim.x) {
+        int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        if (j * (j - 1) / 2 > p) --j;
+        if ((j + 1) * j / 2 <= p) ++j;
+        int i = p - j * (j - 1) / 2;
+        lut[p] = (unsigned short)((j << 6) | i);
+    }
+}
+
 // Pair-dense wave routine for a segment of n <= 64 boxes (the common per-class size): the
 // n(n-1)/2 pairs (i<j) are dealt 64 per step to the lanes, so a 20-box class costs 3 IoU steps
 // instead of 20.  Lane l keeps box l; a pair's two boxes arrive by cross-lane reads.  Every
 // "i suppresses j" sets bit j of row i of a 64x64 bit matrix in LDS (wmask, 64 words of this wave);
 // the greedy order is then resolved with scalar bit operations only.
 __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
-                                               const u64 *keys1, int lo, int n, float thr, u64 *wmask,
-                                               u64 *__restrict__ keys2, int *count2) {
+                                               const u64 *keys1, int lo, int n, const vx_thr &thr, u64 *wmask,
+                                               const unsigned short *pair_lut, u64 *__restrict__ keys2,
+                                               int *count2) {
     const int lane = vx_lane();
     vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
     float ar = 0.f;
@@ -298,12 +336,9 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
         for (int p0 = 0; p0 < npairs; p0 += 64) {
             const int p = p0 + lane;
             const bool pv = p < npairs;
-            // p = j(j-1)/2 + i, 0 <= i < j
-            int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-            if (j * (j - 1) / 2 > p) --j;
-            if ((j + 1) * j / 2 <= p) ++j;
-            int i = p - j * (j - 1) / 2;
-            if (!pv) { i = 0; j = 0; }
+            // p = j(j-1)/2 + i, 0 <= i < j : table built once per workgroup (vx_build_pair_lut)
+            unsigned ij = pv ? pair_lut[p] : 0u;
+            int i = ij & 63, j = ij >> 6;
             float ix1 = __shfl(bx.x, i), iy1 = __shfl(bx.y, i), ix2 = __shfl(bx.z, i), iy2 = __shfl(bx.w, i);
             float ia = __shfl(ar, i);
             float jx1 = __shfl(bx.x, j), jy1 = __shfl(bx.y, j), jx2 = __shfl(bx.z, j), jy2 = __shfl(bx.w, j);
@@ -330,7 +365,7 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
 
 // Wave routine: a segment of n <= 64*WT boxes, everything in registers.
 __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
-                                              const u64 *__restrict__ keys1, int lo, int n, float thr,
+                                              const u64 *__restrict__ keys1, int lo, int n, const vx_thr &thr,
                                               u64 *__restrict__ keys2, int *__restrict__ count2) {
     const int lane = vx_lane();
     float x1[VX_SWEEP_WT], y1[VX_SWEEP_WT], x2[VX_SWEEP_WT], y2[VX_SWEEP_WT], ar[VX_SWEEP_WT];
@@ -375,19 +410,71 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
     }
 }
 
-// Block routine: any segment up to 64*VX_ALIVE_WORDS boxes.  Per 64-box tile: wave 0 resolves the
-// tile against itself (serial over its still-alive boxes, one ballot each) and parks the kept boxes
-// in LDS; then every wave applies those kept boxes to its share of the later tiles.
-struct vx_sweep_smem {
-    u64 alive[VX_ALIVE_WORDS];
-    vx_f4 kbox[64];
-    float karea[64];
-    int kcount;
+// Block routine: any segment up to 64*VX_ALIVE_WORDS boxes, software-pipelined over 64-box tiles.
+// In step t the kept boxes of tile t (parked in LDS, double-buffered) are applied by waves 1.. to
+// their share of tiles t+2.., while wave 0 applies them to tile t+1 and then resolves tile t+1
+// against itself (serial over its still-alive boxes, one ballot each) — the serial resolve is
+// hidden behind the parallel apply, one barrier per tile.
+template <int WORDS>
+struct vx_sweep_smem_t {
+    u64 alive[WORDS];
+    vx_f4 kbox[2][64];
+    float karea[2][64];
+    int kcount[2];
 };
 
-__device__ __forceinline__ void vx_sweep_block(vx_sweep_smem &S, const vx_f4 *__restrict__ sbox,
+typedef vx_sweep_smem_t<VX_ALIVE_WORDS> vx_sweep_smem;               // multi-kernel path: any segment size
+typedef vx_sweep_smem_t<VX_SORT_CHMAX / 64> vx_sweep_smem_image;      // single-launch path: <= 16384 boxes
+
+// lane's survival after the kc kept boxes of buffer `buf`
+template <class SM>
+__device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, const vx_f4 &bx, float a,
+                                              bool al, const vx_thr &thr) {
+    for (int q = 0; q < kc; ++q) {
+        vx_f4 kb = S.kbox[buf][q];
+        float ka = S.karea[buf][q];
+        if (vx_iou_gt(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
+    }
+    return al;
+}
+
+// wave 0: tile t (already hit by every earlier kept box except those in `prev_buf`, if any) ->
+// final kept mask, kept boxes parked in buffer `buf`
+template <class SM>
+__device__ __forceinline__ void vx_resolve_tile(SM &S, const vx_f4 *__restrict__ sbox,
+                                                const float *__restrict__ sarea, int lo, int n, int t, int buf,
+                                                int prev_buf, int prev_kc, const vx_thr &thr) {
+    const int lane = vx_lane();
+    int o = t * 64 + lane;
+    vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+    float a = 0.f;
+    if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
+    u64 al = S.alive[t];
+    if (prev_kc > 0 && al != 0) {
+        bool mine = (al >> lane) & 1ull;
+        al = __ballot(vx_apply_kept(S, prev_buf, prev_kc, bx, a, mine, thr));
+    }
+    u64 todo = al;
+    while (todo) {
+        int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+        float bx1 = vx_bcast(bx.x, i), by1 = vx_bcast(bx.y, i);
+        float bx2 = vx_bcast(bx.z, i), by2 = vx_bcast(bx.w, i), ba = vx_bcast(a, i);
+        bool sup = (lane > i) && vx_iou_gt(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
+        al &= ~__ballot(sup);
+        todo = al & ~((2ull << i) - 1ull);
+    }
+    if ((al >> lane) & 1ull) {
+        int pos = vx_mbcnt(al);
+        S.kbox[buf][pos] = bx;
+        S.karea[buf][pos] = a;
+    }
+    if (lane == 0) { S.alive[t] = al; S.kcount[buf] = __popcll(al); }
+}
+
+template <class SM>
+__device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ sbox,
                                                const float *__restrict__ sarea, const u64 *__restrict__ keys1,
-                                               int lo, int n, float thr, u64 *__restrict__ keys2,
+                                               int lo, int n, const vx_thr &thr, u64 *__restrict__ keys2,
                                                int *__restrict__ count2) {
     const int lane = vx_lane();
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -397,46 +484,22 @@ __device__ __forceinline__ void vx_sweep_block(vx_sweep_smem &S, const vx_f4 *__
         S.alive[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     }
     __syncthreads();
+    if (wave == 0) vx_resolve_tile(S, sbox, sarea, lo, n, 0, 0, 0, 0, thr);
+    __syncthreads();
     for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        const int kc = S.kcount[buf];
         if (wave == 0) {
-            int o = t * 64 + lane;
-            vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
-            float a = 0.f;
-            if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
-            u64 al = S.alive[t];
-            u64 todo = al;
-            while (todo) {
-                int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-                float bx1 = vx_bcast(bx.x, i), by1 = vx_bcast(bx.y, i);
-                float bx2 = vx_bcast(bx.z, i), by2 = vx_bcast(bx.w, i), ba = vx_bcast(a, i);
-                bool sup = (lane > i) && vx_iou_gt(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
-                al &= ~__ballot(sup);
-                todo = al & ~((2ull << i) - 1ull);
-            }
-            if ((al >> lane) & 1ull) {
-                int pos = vx_mbcnt(al);
-                S.kbox[pos] = bx;
-                S.karea[pos] = a;
-            }
-            if (lane == 0) { S.alive[t] = al; S.kcount = __popcll(al); }
-        }
-        __syncthreads();
-        const int kc = S.kcount;
-        if (kc > 0) {
-            for (int u = t + 1 + wave; u < T; u += nw) {
+            if (t + 1 < T) vx_resolve_tile(S, sbox, sarea, lo, n, t + 1, buf ^ 1, buf, kc, thr);
+        } else if (kc > 0) {
+            for (int u = t + 2 + (wave - 1); u < T; u += nw - 1) {
                 u64 au = S.alive[u];
                 if (au == 0) continue;
                 int o = u * 64 + lane;
                 vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
                 float a = 0.f;
                 if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
-                bool al = (au >> lane) & 1ull;
-                for (int q = 0; q < kc; ++q) {
-                    vx_f4 kb = S.kbox[q];
-                    float ka = S.karea[q];
-                    if (vx_iou_gt(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
-                }
-                u64 m = __ballot(al);
+                u64 m = __ballot(vx_apply_kept(S, buf, kc, bx, a, (au >> lane) & 1ull, thr));
                 if (lane == 0) S.alive[u] = m;
             }
         }
@@ -451,7 +514,7 @@ __device__ __forceinline__ void vx_sweep_block(vx_sweep_smem &S, const vx_f4 *__
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
+__global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
                                                       const float *__restrict__ sarea,
                                                       const int *__restrict__ counts, vx_nms_params p,
                                                       u64 *__restrict__ keys2, int *__restrict__ count2) {
@@ -469,18 +532,20 @@ __global__ __launch_bounds__(256) void vx_k_nms_sweep(const u64 *__restrict__ ke
     int *c2 = count2 + b;
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int NC = p.n_classes;
+    const vx_thr T = vx_make_thr(p.thr);
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
     // phase A: groups of nw consecutive classes are dealt round-robin to the image's workgroups;
     // each wave searches its class segment, sweeps it if small, queues it if large
-    for (int c = blockIdx.x * nw + wave; c < NC; c += gridDim.x * nw) {
+    // class c -> workgroup c % gridDim.x, wave (c / gridDim.x) % nw: consecutive classes spread over workgroups
+    for (int c = wave * gridDim.x + blockIdx.x; c < NC; c += gridDim.x * nw) {
         int lo = vx_lower_bound_wave(k1, n, (u64)c << 52);
         if (lo >= n) break;                              // no class >= c left (keys ascending)
         if (vx_key1_cls(k1[lo]) != c) continue;
         int hi = vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52);
         int len = hi - lo;
         if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, k1, lo, len, p.thr, k2, c2);
+            vx_sweep_wave(sb, sa, k1, lo, len, T, k2, c2);
         } else if (vx_lane() == 0) {
             int q = atomicAdd(&s_nbig, 1);
             s_big[q][0] = lo; s_big[q][1] = len;
@@ -489,7 +554,7 @@ __global__ __launch_bounds__(256) void vx_k_nms_sweep(const u64 *__restrict__ ke
     __syncthreads();
     // phase B: large segments, whole workgroup each
     const int nbig = s_nbig;
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], p.thr, k2, c2);
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], T, k2, c2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -515,11 +580,12 @@ struct vx_image_args {
 
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
-    __shared__ vx_sweep_smem S;
+    __shared__ vx_sweep_smem_image S;
     __shared__ int s_big[VX_SWEEP_MAXBIG][2];
     __shared__ int s_nbig, s_count2, s_nseg;
     __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
     __shared__ u64 s_wmask[16][64];
+    __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
     const vx_nms_params &p = a.p;
     const int b = blockIdx.x, nt = blockDim.x;
     const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
@@ -543,6 +609,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
     if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; }
+    vx_build_pair_lut(s_pair_lut);
     __syncthreads();
     VX_STAMP(1);
     vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
@@ -561,6 +628,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __syncthreads();
     VX_STAMP(3);
     u64 *k2 = a.keys2 + ob;
+    const vx_thr T = vx_make_thr(p.thr);
     const int wave = threadIdx.x >> 6, nw = nt >> 6, lane = vx_lane();
     // ordered list of class-segment starts: boundary flags -> per-64-group counts -> scan -> scatter
     int *seg = a.seg + (long long)b * VX_MAX_CLASSES;
@@ -598,9 +666,9 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         int hi = s + 1 < nseg ? seg[s + 1] : n;
         int len = hi - lo;
         if (len <= 64) {
-            vx_sweep_pairs(sb, sa, sk, lo, len, p.thr, s_wmask[wave], k2, &s_count2);
+            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, k2, &s_count2);
         } else if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, sk, lo, len, p.thr, k2, &s_count2);
+            vx_sweep_wave(sb, sa, sk, lo, len, T, k2, &s_count2);
         } else if (lane == 0) {
             int q = atomicAdd(&s_nbig, 1);
             if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; }
@@ -609,7 +677,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __syncthreads();
     VX_STAMP(4);
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], p.thr, k2, &s_count2);
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], T, k2, &s_count2);
     __syncthreads();
     VX_STAMP(5);
     // kept keys back into global score order, then the outputs
@@ -753,11 +821,14 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     int rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
     vx_prof_end(VX_PROF_SORT1, st);
     if (rc != VX_OK) return rc;
-    int X = (n_classes + 7) / 8;          // 2 class groups of 4 waves per workgroup ...
-    if (X > 32) X = 32;                   // ... capped: 4096 classes / 32 = 128 = VX_SWEEP_MAXBIG
+    // few classes -> few, long segments: 16 waves per segment; many classes -> many segments side by side
+    // (4 waves each).  One class per wave and pass; <= 4096/32 = 128 = VX_SWEEP_MAXBIG classes per workgroup.
+    const int sweep_threads = n_classes <= 8 ? 1024 : 256;
+    int X = n_classes <= 8 ? n_classes : (n_classes + 3) / 4;
+    if (X > 32) X = 32;
     if (X < 1) X = 1;
     vx_prof_begin(VX_PROF_SWEEP, st);
-    hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(256), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
+    hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
                        w.count2);
     vx_prof_end(VX_PROF_SWEEP, st);
     vx_prof_begin(VX_PROF_SORT2, st);
