@@ -241,48 +241,92 @@ __device__ __forceinline__ int vx_fused_tile_row0(const vx_fused_params &p, int 
 }
 
 template <int V>
+struct vx_cells { float v[V]; };
+
+template <int V, bool NT>
+__device__ __forceinline__ vx_cells<V> vx_load_cells(const float *p) {
+    vx_cells<V> c;
+    if constexpr (V == 4) {
+        vx_v4 q;
+        if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(p));
+        else q = *reinterpret_cast<const vx_v4 *>(p);
+        c.v[0] = q.x; c.v[1] = q.y; c.v[2] = q.z; c.v[3] = q.w;
+    } else {
+        if constexpr (NT) c.v[0] = __builtin_nontemporal_load(p);
+        else c.v[0] = *p;
+    }
+    return c;
+}
+
+// VX_FUSED_UN: channel planes per register batch (UN x 1 KiB per wave in flight per batch)
+template <int V, int VX_FUSED_UN, bool NT>
 __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx_scale_desc &s, int b, int a,
                                               int cell0, int row0, int tile, vx_rec *stage, int *tile_counts,
                                               int *status) {
     const int lane = vx_lane();
     const int c0 = cell0 + lane * V;                 // first cell of this lane
     const bool live = c0 < s.cells;                  // cells % V == 0 -> all V cells live or none
-    const float *plane = s.ptr + ((long long)(b * 3 + a) * p.NP) * s.cells + c0;
-    float tb[5][V];
+    const long long cells = s.cells;
+    const float *plane = s.ptr + ((long long)(b * 3 + a) * p.NP) * cells + c0;
     float best[V];
     int bi[V];
     bool nan = false;
 #pragma unroll
     for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    vx_cells<V> tb[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch)
+#pragma unroll
+        for (int j = 0; j < V; ++j) tb[ch].v[j] = 0.f;
     if (live) {
+        const int C = p.C;
+        const float *cp = plane + 5 * cells;
+        // Two register batches in ping-pong: batch B is requested before batch A is consumed, so every
+        // wave always has 8..16 KiB of loads in flight.
+        vx_cells<V> A[VX_FUSED_UN], Bt[VX_FUSED_UN];
 #pragma unroll
-        for (int ch = 0; ch < 5; ++ch) {
-            if (V == 4) {
-                vx_f4 v = *reinterpret_cast<const vx_f4 *>(plane + (long long)ch * s.cells);
-                tb[ch][0] = v.x; tb[ch][1 % V] = v.y; tb[ch][2 % V] = v.z; tb[ch][3 % V] = v.w;
-            } else {
-                tb[ch][0] = plane[(long long)ch * s.cells];
+        for (int u = 0; u < VX_FUSED_UN; ++u)
+            if (u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)u * cells);
+#pragma unroll
+        for (int ch = 0; ch < 5; ++ch) tb[ch] = vx_load_cells<V, NT>(plane + (long long)ch * cells);
+        for (int k0 = 0; k0 < C; k0 += 2 * VX_FUSED_UN) {
+#pragma unroll
+            for (int u = 0; u < VX_FUSED_UN; ++u)
+                if (k0 + VX_FUSED_UN + u < C) Bt[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + VX_FUSED_UN + u) * cells);
+#pragma unroll
+            for (int u = 0; u < VX_FUSED_UN; ++u) {
+                const int k = k0 + u;
+                if (k < C) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        float v = A[u].v[j];
+                        nan |= (v != v);
+                        float sg = vx_sigmoid(v);
+                        if (sg > best[j] || k == 0) { best[j] = sg; bi[j] = k; }
+                    }
+                }
             }
 #pragma unroll
-            for (int j = 0; j < V; ++j) nan |= (tb[ch][j] != tb[ch][j]);
+            for (int u = 0; u < VX_FUSED_UN; ++u)
+                if (k0 + 2 * VX_FUSED_UN + u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + 2 * VX_FUSED_UN + u) * cells);
+#pragma unroll
+            for (int u = 0; u < VX_FUSED_UN; ++u) {
+                const int k = k0 + VX_FUSED_UN + u;
+                if (k < C) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        float v = Bt[u].v[j];
+                        nan |= (v != v);
+                        float sg = vx_sigmoid(v);
+                        if (sg > best[j]) { best[j] = sg; bi[j] = k; }
+                    }
+                }
+            }
         }
-        const float *cp = plane + 5LL * s.cells;
-#pragma unroll 8
-        for (int k = 0; k < p.C; ++k) {
-            float v[V];
-            if (V == 4) {
-                vx_f4 q = *reinterpret_cast<const vx_f4 *>(cp + (long long)k * s.cells);
-                v[0] = q.x; v[1 % V] = q.y; v[2 % V] = q.z; v[3 % V] = q.w;
-            } else {
-                v[0] = cp[(long long)k * s.cells];
-            }
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                nan |= (v[j] != v[j]);
-                float sg = vx_sigmoid(v[j]);
-                if (sg > best[j] || k == 0) { best[j] = sg; bi[j] = k; }
-            }
-        }
+        for (int ch = 0; ch < 5; ++ch)
+#pragma unroll
+            for (int j = 0; j < V; ++j) nan |= (tb[ch].v[j] != tb[ch].v[j]);
     }
     if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
     float obj[V];
@@ -291,7 +335,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
     int below = 0, total = 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        obj[j] = live ? vx_sigmoid(tb[4][j]) : 0.f;
+        obj[j] = live ? vx_sigmoid(tb[4].v[j]) : 0.f;
         pass[j] = live && (p.use_thr ? (obj[j] > p.thr) : true);
         m[j] = __ballot(pass[j]);
         below += vx_mbcnt(m[j]);
@@ -302,10 +346,10 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
     for (int j = 0; j < V; ++j) {
         if (pass[j]) {
             int gc = c0 + j;
-            float cx = vx_yolo_xy(tb[0][j], (float)(gc % s.G), s.stride);
-            float cy = vx_yolo_xy(tb[1][j], (float)(gc / s.G), s.stride);
-            float w = vx_yolo_wh(tb[2][j], s.aw[a], s.stride);
-            float h = vx_yolo_wh(tb[3][j], s.ah[a], s.stride);
+            float cx = vx_yolo_xy(tb[0].v[j], (float)(gc % s.G), s.stride);
+            float cy = vx_yolo_xy(tb[1].v[j], (float)(gc / s.G), s.stride);
+            float w = vx_yolo_wh(tb[2].v[j], s.aw[a], s.stride);
+            float h = vx_yolo_wh(tb[3].v[j], s.ah[a], s.stride);
             int row = row0 + lane * V + j;
             stage[(long long)b * p.R + row0 + pos] = vx_yolo_record(cx, cy, w, h, obj[j], best[j], bi[j], row, p.img_size);
             ++pos;
@@ -314,6 +358,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
     if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
 }
 
+template <int UN, bool NT>
 __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
                                                        int *__restrict__ tile_counts, int *__restrict__ status) {
     long long wtile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -323,17 +368,9 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec
     int t = (int)(wtile - (long long)b * p.tiles_per_img);
     int si, a, cell0;
     int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
-    // wave-uniform dispatch on the scale's vector width
-    if (si == 0) {
-        if (p.s[0].vec) vx_fused_tile<4>(p, p.s[0], b, a, cell0, row0, t, stage, tile_counts, status);
-        else vx_fused_tile<1>(p, p.s[0], b, a, cell0, row0, t, stage, tile_counts, status);
-    } else if (si == 1) {
-        if (p.s[1].vec) vx_fused_tile<4>(p, p.s[1], b, a, cell0, row0, t, stage, tile_counts, status);
-        else vx_fused_tile<1>(p, p.s[1], b, a, cell0, row0, t, stage, tile_counts, status);
-    } else {
-        if (p.s[2].vec) vx_fused_tile<4>(p, p.s[2], b, a, cell0, row0, t, stage, tile_counts, status);
-        else vx_fused_tile<1>(p, p.s[2], b, a, cell0, row0, t, stage, tile_counts, status);
-    }
+    const vx_scale_desc &s = p.s[si];                 // wave-uniform
+    if (s.vec) vx_fused_tile<4, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
+    else vx_fused_tile<1, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -554,7 +591,10 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     if (nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_FUSED, st);
-    hipLaunchKernelGGL(vx_k_yolo_fused, dim3((unsigned)nblk), dim3(256), 0, st, p, stage, tile_counts, d_status);
+    // <2, true>: 2 channel planes per register batch in ping-pong (7 waves/SIMD), non-temporal loads.
+    // A/B on MI355X, B=256 (tools/ab_fused.py): UN 8/4/3/2/1 with nt = 5.0/5.9/5.9/6.19/5.96 TB/s, UN 4/2 plain = 5.5/5.67.
+    hipLaunchKernelGGL((vx_k_yolo_fused<2, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage, tile_counts,
+                       d_status);
     vx_prof_end(VX_PROF_FUSED, st);
     vx_finish_params f;
     f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;
