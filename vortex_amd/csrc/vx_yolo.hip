@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__rest
         for (int q = threadIdx.x; q < nq; q += 256) {
             int ch = q >> 4, c4 = (q & 15) * 4;
             if (c4 < ncell) {
-                vx_f4 v = *reinterpret_cast<const vx_f4 *>(plane + (long long)ch * p.cells + c4);
+                vx_v4 v = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(plane + (long long)ch * p.cells + c4));
                 float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__rest
     for (int k = threadIdx.x; k < nchunk; k += 256) {
         int i = k * 4;
         if (i >= shift && i + 4 <= shift + n) {
-            *reinterpret_cast<vx_f4 *>(gbase + i) = *reinterpret_cast<const vx_f4 *>(tile + i);
+            __builtin_nontemporal_store(*reinterpret_cast<const vx_v4 *>(tile + i), reinterpret_cast<vx_v4 *>(gbase + i));
         } else {
             for (int j = 0; j < 4; ++j)
                 if (i + j >= shift && i + j < shift + n) gbase[i + j] = tile[i + j];
@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__rest
     for (int k = threadIdx.x; k < nchunk; k += 256) {
         int i = k * 4;
         if (i >= shift && i + 4 <= shift + n) {
-            vx_f4 v = *reinterpret_cast<const vx_f4 *>(gbase + i);
+            vx_v4 v = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(gbase + i));
             nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-            *reinterpret_cast<vx_f4 *>(tile + i) = v;
+            *reinterpret_cast<vx_v4 *>(tile + i) = v;
         } else {
             for (int j = 0; j < 4; ++j)
                 if (i + j >= shift && i + j < shift + n) {
