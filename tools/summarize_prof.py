@@ -19,8 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    f = glob.glob(pattern, recursive=True)
-    return f[0] if f else None
+    f = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None      # newest: gpurun merges every call's files into gpurun_out/
+
+
+def kname(full):
+    """'void vx_k_yolo_fused<2, true>(vx_fused_params, ...)' -> 'vx_k_yolo_fused' (rocprofv3 prints the
+    return type and template arguments of template kernels)."""
+    n = full.strip().strip('"')
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("(")[0].split("<")[0]
 
 
 def pmc(path, counter):
@@ -29,7 +38,7 @@ def pmc(path, counter):
         return {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
@@ -40,7 +49,7 @@ def main(src, tag, rnd, workload):
     if ks:
         rows = list(csv.reader(open(ks)))
         head, body = rows[0], rows[1:]
-        body.sort(key=lambda r: (not r[0].startswith("vx_"), -float(r[2])))
+        body.sort(key=lambda r: (not kname(r[0]).startswith("vx_"), -float(r[2])))
         with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
             csv.writer(f).writerows([head] + body)
     b = os.path.join(src, "bench_stats.json")
