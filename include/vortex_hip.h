@@ -145,6 +145,18 @@ int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d
                    int out_capacity, int32_t *d_status,
                    void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------- DETR post-process
+ * Replaces DETRPostProcess.forward / _process_single_batch (networks/models/detection/detr.py:539-559)
+ * and cxcywh_to_xyxy (detr.py:932-936) for all images in one launch.
+ *   d_in f32[B,Q,4+n_logits]: per query (cx,cy,w,h) then n_logits logits, the last one = "no object".
+ * Per query: p = softmax(logits); conf,label = max / first argmax of p[0 .. n_logits-2];
+ * kept iff conf > score_threshold (strict); row = (cx-w/2, cy-h/2, cx+w/2, cy+h/2, conf, float(label)).
+ *   d_out f32[B,Q,6]: the kept rows of image b, in query order, at d_out[b][0 .. d_counts[b]).
+ *   d_counts i32[B].
+ * Tolerance class (softmax/exp): 1e-5 relative on conf; boxes and labels exact. */
+int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_threshold,
+                   float *d_out, int32_t *d_counts, void *stream);
+
 /* ---------------------------------------------------------------- tuple packing
  * The `tuple(results)` of BatchedNMSPostProcess.forward (base_postprocess.py:131-138) as one launch:
  * rows [0, min(d_counts[b],capacity)) of d_src f32[B,capacity,D] are copied back to back into d_dst
@@ -156,8 +168,11 @@ int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacit
  * counterpart; bench.py's roofline leg).  When enabled, every kernel family launched by this library is
  * bracketed by HIP events recorded on the launch stream (events are created here, once, outside the
  * data path); vx_profile_get synchronises on them and returns the summed / min / max kernel time of
- * the launches recorded since the last vx_profile_enable.  Process-global, not thread-safe. */
+ * the launches recorded since the last vx_profile_enable.  Process-global, not thread-safe.
+ * Each event pair costs a few microseconds of stream time; vx_profile_select restricts the bracketing to
+ * the slots whose bit is set in slot_mask (default: all), e.g. only the dominant kernel inside a timed run. */
 int vx_profile_enable(int max_launches_per_kernel);
+int vx_profile_select(unsigned slot_mask);
 int vx_profile_disable(void);
 int vx_profile_slots(void);
 int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, float *min_ms, float *max_ms);

@@ -381,6 +381,35 @@ def get_prediction_results(results, output_format):
     return final
 
 
+# --------------------------------------------------------------------------- §8f-1 DETR
+def detr_postprocess(inputs: torch.Tensor, score_threshold: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+    """DETRPostProcess.forward / _process_single_batch (networks/models/detection/detr.py:539-559) with
+    cxcywh_to_xyxy (detr.py:932-936): softmax over all logits, max over all but the last ("no object"),
+    strict threshold on that probability, rows kept in query order."""
+    if inputs.ndim != 3:
+        raise RuntimeError("DETR postprocess input must have dimension of 3 "
+                           "(num_batch, num_queries, (num_classes + 1) + 4)")
+    out = []
+    for x in inputs:
+        x_c, y_c, w, h = x[:, :4].unbind(-1)
+        bbox = torch.stack([(x_c - 0.5 * w), (y_c - 0.5 * h), (x_c + 0.5 * w), (y_c + 0.5 * h)], dim=-1)
+        probas = x[:, 4:].softmax(-1)[:, :-1]
+        conf, labels = probas.max(-1, keepdim=True)
+        keep = (conf > score_threshold).flatten()
+        out.append(torch.cat((bbox, conf, labels.float()), -1)[keep])
+    return tuple(out)
+
+
+def synth_detr_outputs(B: int, Q: int = 100, n_logits: int = 92, seed: int = 0) -> torch.Tensor:
+    """DETR head output [B,Q,4+n_logits]: boxes sigmoid(N(0,1)) (cx,cy,w,h in 0..1), class logits N(0,2),
+    no-object logit N(2,2) (most queries are background, as after training)."""
+    g = torch.Generator().manual_seed(seed)
+    box = torch.sigmoid(torch.randn(B, Q, 4, generator=g))
+    lg = torch.randn(B, Q, n_logits, generator=g) * 2
+    lg[..., -1] += 2
+    return torch.cat((box, lg), -1).contiguous()
+
+
 # --------------------------------------------------------------------------- synthetic inputs (SURVEY.md §8d)
 def synth_images(B: int, S: int, seed: int = 0) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)

@@ -44,14 +44,25 @@ tv = types.ModuleType("torchvision")
 tvo = types.ModuleType("torchvision.ops")
 tvo.nms = O.nms
 tv.ops = tvo
+tv.__version__ = "0.10.1"                        # detr.py:10 parses it (pinned torchvision<=0.10.1)
 sys.modules["torchvision"] = tv
 sys.modules["torchvision.ops"] = tvo
+# detr.py:17,20 import easydict and the backbone registry at module scope; DETRPostProcess uses neither.
+ed = types.ModuleType("easydict")
+ed.EasyDict = dict
+sys.modules["easydict"] = ed
+bb = types.ModuleType("vortex.development.networks.modules.backbones")
+bb.get_backbone = None
+sys.modules["vortex.development.networks.modules.backbones"] = bb
+_stub("vortex.development.networks.models", R + "/networks/models")
+_stub("vortex.development.networks.models.detection", R + "/networks/models/detection")
 
 from vortex.development.networks.modules.preprocess.normalizer import Normalize, FlipNormalize  # noqa: E402
 from vortex.development.networks.modules.heads.detection.yolov3 import YoloV3Layer  # noqa: E402
 from vortex.development.networks.modules.postprocess.yolov3 import YoloV3Decoder, YoloV3PostProcess  # noqa: E402
 from vortex.development.networks.modules.postprocess.utils.nms import batched_nms, BatchedNMS  # noqa: E402
 from vortex.development.networks.modules.utils.darknet import yolo_feature_maps  # noqa: E402
+from vortex.development.networks.models.detection.detr import DETRPostProcess  # noqa: E402
 
 
 def np_(t):
@@ -156,8 +167,43 @@ def gen_batched_nms():
     np.savez_compressed(os.path.join(HERE, "batched_nms.npz"), **out)
 
 
+def _reference_test_tensors():
+    """pred_bbox / pred_logits literals of the reference's own tests/models/test_detr.py:12-37 (data)."""
+    import ast
+    tree = ast.parse(open("/root/reference/tests/models/test_detr.py").read())
+    vals = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) in ("pred_bbox", "pred_logits"):
+            vals[node.targets[0].id] = torch.tensor(ast.literal_eval(node.value.args[0]))
+    return vals["pred_bbox"], vals["pred_logits"]
+
+
+def gen_detr():
+    """DETRPostProcess of the reference on (a) the tensors of its own test (threshold 0.3,
+    tests/models/test_detr.py:124-145) and (b) seeded COCO-shaped head outputs."""
+    pp = DETRPostProcess()
+    assert pp.additional_inputs == (("score_threshold", (1,)),)
+    out = {}
+    pb, pl = _reference_test_tensors()
+    x = torch.cat((pb, pl), -1)
+    out["ref_in"] = np_(x)
+    res = pp(x, score_threshold=torch.tensor(0.3))
+    for b, r in enumerate(res):
+        out[f"ref_t30_b{b}"] = np_(r)
+    for name, B, Q, NL, seed in (("coco", 4, 100, 92, 11), ("small", 3, 7, 2, 12), ("wide", 2, 300, 366, 13)):
+        x = O.synth_detr_outputs(B, Q, NL, seed)
+        out["in_" + name] = np_(x)
+        for tname, thr in (("t30", 0.3), ("t70", 0.7), ("t00", 0.0), ("t100", 1.0)):
+            res = pp(x, score_threshold=torch.tensor([thr]))
+            assert isinstance(res, tuple) and len(res) == B
+            for b, r in enumerate(res):
+                out[f"{name}_{tname}_b{b}"] = np_(r)
+    np.savez_compressed(os.path.join(HERE, "detr.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    gen_detr()
     gen_normalize()
     gen_yolo_layer()
     gen_decoder_and_postprocess()

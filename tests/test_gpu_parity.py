@@ -209,6 +209,25 @@ def test_batched_nms_vs_oracle(K, C, thr, seed):
                                   scores=scores.to(DEV), iou_threshold=torch.tensor([thr])), det[:, ref[:100]])
 
 
+@pytest.mark.parametrize("base", [0.5, 0.25, 1.0 / 3.0, 0.2, 2.0 / 7.0, 1e-7, 0.999999])
+def test_batched_nms_iou_exactly_at_threshold(base):
+    """Integer-grid boxes: intersections and unions are exact small integers, so many pairs have an IoU whose
+    fp32 quotient EQUALS the threshold or sits one ulp either side of it -- the cases where the kernel's
+    division-free bracket must hand over to the IEEE division (strict '>' as in the reference)."""
+    g = torch.Generator().manual_seed(int(base * 1e6) % 9973)
+    K = 1500
+    xy = torch.randint(0, 12, (K, 2), generator=g).float()
+    wh = torch.randint(1, 8, (K, 2), generator=g).float()
+    boxes = torch.cat((xy, xy + wh), 1).contiguous()
+    scores = torch.rand(K, generator=g)
+    cls = torch.randint(0, 3, (K,), generator=g)
+    t0 = np.float32(base)
+    for thr in (t0, np.nextafter(t0, np.float32(0)), np.nextafter(t0, np.float32(2))):
+        thr_t = torch.tensor([float(thr)])
+        ref = O.batched_nms(boxes, scores, cls, thr_t)
+        same(V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), thr_t), ref)
+
+
 def test_nms_class_agnostic_module():
     boxes, scores, _ = O.synth_stress_boxes(1500, 1, 9)
     det = torch.randn(1, 1500, 6)
@@ -297,6 +316,50 @@ def test_prior_decode_and_postprocess(L, NL, P, B, sthr):
         keep = O.batched_nms(gb, gs, gc, torch.tensor([0.4]))
         same(res[b], c.det[b, :k].cpu()[keep])
         assert res[b].shape[1] == 6 + 2 * L
+
+
+# ------------------------------------------------------------------------------------------- DETR (§8f-1)
+def _detr_check(x, thr, expected):
+    """conf within 1e-5 rel (softmax/exp), boxes and labels exact, same rows kept in the same order.  A query
+    whose oracle conf lies within 2e-5 rel of the threshold may fall either side of the strict compare (that
+    is the tolerance class); such rows are removed from both sides, every other row must match."""
+    allrows = O.detr_postprocess(x, torch.tensor(-1.0))
+    pp = V.DETRPostProcess().to(DEV)
+    assert pp.additional_inputs == (("score_threshold", (1,)),)
+    res = pp(x.to(DEV), score_threshold=torch.tensor([thr]))
+    assert isinstance(res, tuple) and len(res) == x.shape[0]
+    n_amb = 0
+    for r, e, a in zip(res, expected, allrows):
+        e, r = torch.as_tensor(e), r.cpu()
+        assert r.dtype == torch.float32 and r.ndim == 2 and r.shape[1] == 6
+        amb = a[(a[:, 4] - thr).abs() <= 2e-5 * max(thr, 1e-3)][:, :4]
+        if amb.shape[0]:
+            n_amb += amb.shape[0]
+            e = e[~(e[:, None, :4] == amb[None]).all(-1).any(-1)]
+            r = r[~(r[:, None, :4] == amb[None]).all(-1).any(-1)]
+        assert r.shape == e.shape, (r.shape, e.shape)
+        same(r[:, :4], e[:, :4]); same(r[:, 5], e[:, 5]); close(r[:, 4], e[:, 4])
+    assert n_amb <= 1 + x.shape[0] * x.shape[1] // 2000
+
+
+@pytest.mark.parametrize("name", ["coco", "small", "wide"])
+@pytest.mark.parametrize("tname,thr", [("t30", 0.3), ("t70", 0.7), ("t00", 0.0), ("t100", 1.0)])
+def test_detr_postprocess_golden(golden, name, tname, thr):
+    g = golden("detr")
+    x = torch.from_numpy(g["in_" + name])
+    _detr_check(x, thr, [g[f"{name}_{tname}_b{b}"] for b in range(x.shape[0])])
+
+
+def test_detr_postprocess_reference_test_and_shapes(golden):
+    g = golden("detr")
+    x = torch.from_numpy(g["ref_in"])
+    _detr_check(x, 0.3, [g[f"ref_t30_b{b}"] for b in range(x.shape[0])])
+    _detr_check(x[:1], 0.3, [g["ref_t30_b0"]])                  # single image (test_detr.py:128-131)
+    with pytest.raises(RuntimeError):
+        V.DETRPostProcess()(x[0].to(DEV), score_threshold=torch.tensor(0.3))
+    for B, Q, NL, seed in ((256, 100, 92, 3), (2, 900, 92, 4), (5, 257, 1203 + 1, 5), (1, 1, 2, 6)):
+        x = O.synth_detr_outputs(B, Q, NL, seed)
+        _detr_check(x, 0.5, O.detr_postprocess(x, torch.tensor([0.5])))
 
 
 # ------------------------------------------------------------------------------------------- callers

@@ -155,3 +155,37 @@ def test_resize_identity_and_letterbox():
     assert np.all(O.resize_bilinear_u8(const, 16, 16) == 200)
     batch = O.resize_batch([img, const], (4, 16, 16, 3))
     assert batch.shape == (4, 16, 16, 3) and np.all(batch[2:] == 0)
+
+
+# --------------------------------------------------------------------------- §8f-1 DETR
+def test_detr_oracle_equals_reference_golden(golden):
+    g = golden("detr")
+    x = torch.from_numpy(g["ref_in"])
+    res = O.detr_postprocess(x, torch.tensor(0.3))
+    assert isinstance(res, tuple) and len(res) == x.shape[0]
+    for b, r in enumerate(res):
+        assert r.shape[1] == 6
+        assert np.array_equal(r.numpy(), g[f"ref_t30_b{b}"])
+    for name in ("coco", "small", "wide"):
+        x = torch.from_numpy(g["in_" + name])
+        for tname, thr in (("t30", 0.3), ("t70", 0.7), ("t00", 0.0), ("t100", 1.0)):
+            res = O.detr_postprocess(x, torch.tensor([thr]))
+            for b, r in enumerate(res):
+                assert np.array_equal(r.numpy(), g[f"{name}_{tname}_b{b}"]), (name, tname, b)
+    assert g["coco_t100_b0"].shape == (0, 6)
+
+
+def test_detr_reference_test_expectation(golden):
+    """The expectation of the reference's own test (tests/models/test_detr.py:136-145), recomputed from
+    its input tensors: xyxy box | max softmax prob of the foreground classes | label, conf > 0.3."""
+    x = torch.from_numpy(golden("detr")["ref_in"])
+    det = O.detr_postprocess(x, torch.tensor(0.3))
+    for b in range(x.shape[0]):
+        bbox, logits = x[b, :, :4], x[b, :, 4:]
+        xyxy = torch.stack((bbox[:, 0] - 0.5 * bbox[:, 2], bbox[:, 1] - 0.5 * bbox[:, 3],
+                            bbox[:, 0] + 0.5 * bbox[:, 2], bbox[:, 1] + 0.5 * bbox[:, 3]), -1)
+        conf, labels = logits.softmax(-1)[:, :-1].max(-1)
+        exp = torch.cat((xyxy, conf.unsqueeze(1), labels.float().unsqueeze(1)), -1)[conf > 0.3]
+        assert torch.equal(exp, det[b])
+    with pytest.raises(RuntimeError):
+        O.detr_postprocess(x[0], torch.tensor(0.3))

@@ -9,7 +9,7 @@ reference's own nn.Module API for that path:
                 YoloV3PostProcess / YoloV3FusedPostProcess
     prior.PriorBoxDecoder / PriorBoxPostProcess
     predictor.BasePredictor / create_predictor / get_prediction_results
-    runtime.resize_batch / adjust_coordinates
+    detr.DETRPostProcess
     parallel.shard_batch / allgather_detections
 """
 from . import _lib, ops  # noqa: F401
@@ -19,6 +19,7 @@ from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostPro
                           BatchedNMSPostProcess, YoloV3PostProcess, YoloV3FusedPostProcess,
                           NoOpPostProcess, batched_nms, get_postprocess)
 from .prior import PriorBoxDecoder, PriorBoxPostProcess  # noqa: F401
+from .detr import DETRPostProcess  # noqa: F401
 from .predictor import BasePredictor, create_predictor, get_prediction_results  # noqa: F401
 
 __version__ = "0.1.0"

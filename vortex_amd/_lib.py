@@ -46,8 +46,10 @@ _SIGNATURES = {
     "vx_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "vx_detr_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vx_profile_enable": (c_int, [c_int]),
+    "vx_profile_select": (c_int, [ctypes.c_uint]),
     "vx_profile_disable": (c_int, []),
     "vx_profile_slots": (c_int, []),
     "vx_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_int),
@@ -111,8 +113,20 @@ def f18(v):
     return _F18(*[float(x) for x in v])
 
 
-def profile_enable(max_launches: int = 4096):
+def profile_enable(max_launches: int = 4096, only=None):
+    """Bracket kernel launches with HIP events; `only` = iterable of kernel-family names to restrict to."""
     check(lib().vx_profile_enable(int(max_launches)), "vx_profile_enable")
+    mask = 0xFFFFFFFF
+    if only is not None:
+        only, mask = set(only), 0
+        for i in range(lib().vx_profile_slots()):
+            name, n = ctypes.c_char_p(), c_int()
+            tot, mn, mx = c_float(), c_float(), c_float()
+            check(lib().vx_profile_get(i, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tot), ctypes.byref(mn),
+                                       ctypes.byref(mx)), "vx_profile_get")
+            if name.value.decode() in only:
+                mask |= 1 << i
+    check(lib().vx_profile_select(mask), "vx_profile_select")
 
 
 def profile_disable():

@@ -29,20 +29,22 @@ struct Slot {
     int cap = 0;
 };
 Slot g_slots[VX_PROF_NSLOTS];
+unsigned g_mask = ~0u;               // slots that record events (vx_profile_select)
 const char *g_names[VX_PROF_NSLOTS] = {
     "vx_k_normalize/resize", "vx_k_yolo_head_decode", "vx_k_yolo_decode_rows", "vx_k_yolo_fused",
     "vx_k_cand_finish", "vx_k_prior_decode", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather",
-    "vx_k_nms_sweep", "vx_k_sort(keys2)+output", "vx_k_pack_rows", "vx_k_nms_image"};
+    "vx_k_nms_sweep", "vx_k_sort(keys2)+output", "vx_k_pack_rows", "vx_k_nms_image",
+    "vx_k_detr_decode"};
 }  // namespace
 
 void vx_prof_begin_impl(int slot, hipStream_t st) {
     Slot &s = g_slots[slot];
-    if (s.launches >= s.cap) return;
+    if (s.launches >= s.cap || !((g_mask >> slot) & 1u)) return;
     (void)hipEventRecord(s.ev[2 * s.launches], st);
 }
 void vx_prof_end_impl(int slot, hipStream_t st) {
     Slot &s = g_slots[slot];
-    if (s.launches >= s.cap) return;
+    if (s.launches >= s.cap || !((g_mask >> slot) & 1u)) return;
     (void)hipEventRecord(s.ev[2 * s.launches + 1], st);
     ++s.launches;
 }
@@ -60,6 +62,11 @@ extern "C" int vx_profile_enable(int max_launches_per_kernel) {
         s.launches = 0;
     }
     vx_prof_on = true;
+    return VX_OK;
+}
+
+extern "C" int vx_profile_select(unsigned slot_mask) {
+    g_mask = slot_mask;
     return VX_OK;
 }
 

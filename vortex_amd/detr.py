@@ -1,0 +1,34 @@
+"""DETR post-process behind the reference's module API (networks/models/detection/detr.py:531-559)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .postprocess import PendingDetections, _f, finish_results
+
+
+class DETRPostProcess(nn.Module):
+    """Same constructor, `additional_inputs`, forward signature, error and return type (tuple of
+    f32[K_i, 6] = x1,y1,x2,y2,conf,label in query order) as the reference; all images in one launch."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.additional_inputs = (
+            ('score_threshold', (1,)),
+        )
+
+    def forward_device(self, inputs: torch.Tensor, score_threshold):
+        if inputs.ndim != 3:
+            raise RuntimeError("DETR postprocess input must have dimension of 3 "
+                               "(num_batch, num_queries, (num_classes + 1) + 4)")
+        if inputs.size(0) == 0:
+            raise RuntimeError("DETR postprocess needs at least one image")
+        rows, meta = ops.detr_decode(inputs, _f(score_threshold))
+        B = inputs.size(0)
+        return ops.pack_rows(rows, meta[B:2 * B]), meta
+
+    def forward_async(self, inputs: torch.Tensor, score_threshold, **kwargs) -> PendingDetections:
+        return PendingDetections(*self.forward_device(inputs, score_threshold))
+
+    @torch.no_grad()
+    def forward(self, inputs: torch.Tensor, score_threshold: torch.Tensor, **kwargs) -> torch.Tensor:
+        return finish_results(*self.forward_device(inputs, score_threshold))

@@ -202,6 +202,20 @@ def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+def detr_decode(inputs: torch.Tensor, score_threshold: float):
+    """f32[B,Q,4+n_logits] -> (rows f32[B,Q,6] compacted per image in query order, meta i32[2B+1] with the
+    per-image row counts at [B:2B], same layout as the NMS paths so finish_results() applies)."""
+    L.require_cuda(inputs, "inputs")
+    x = inputs.contiguous().float()
+    B, Q, ncol = x.shape
+    out = torch.empty((B, Q, 6), dtype=torch.float32, device=x.device)
+    meta = torch.zeros(2 * B + 1, dtype=torch.int32, device=x.device)
+    rc = L.lib().vx_detr_decode(x.data_ptr(), B, Q, ncol - 4, float(score_threshold), out.data_ptr(),
+                                meta[B:2 * B].data_ptr(), L.stream_ptr(x.device))
+    L.check(rc, "vx_detr_decode")
+    return out, meta
+
+
 def raise_on_status(status: int):
     """Map device status bits to the reference's exceptions."""
     if status & L.VX_STATUS_NAN:
