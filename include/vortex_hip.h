@@ -41,6 +41,8 @@ extern "C" {
 #define VX_MAX_CANDIDATES     1048575 /* per image; sort key holds the index in 20 bits  */
 #define VX_MAX_COORDINATE     2048  /* postprocess/utils/nms.py:94 */
 
+#define VX_MAX_FORMAT_COLS    64    /* columns of one formatted result row                */
+
 #define VX_RESIZE_STRETCH     0     /* src/runtime/vortex/runtime/basic_runtime.py:66-68 */
 #define VX_RESIZE_LETTERBOX   1     /* build-side extension (basic_runtime.py:70-73 is a TODO) */
 
@@ -62,6 +64,12 @@ int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst,
                                 int B, int Hs, int Ws, int Hd, int Wd,
                                 const float mean[3], const float std[3], int scaler,
                                 int flip, int resize_mode, int pad_value, void *stream);
+
+/* Resize only: BaseRuntime.resize_stretch / resize_batch (src/runtime/vortex/runtime/basic_runtime.py:66-68,
+ * :75-90; cv2.resize default INTER_LINEAR).  d_src u8[B,Hs,Ws,3] -> d_dst u8[B,Hd,Wd,3], same fixed-point
+ * scheme as above (parity unpinned: cv2 is not available to pin it). */
+int vx_resize_u8hwc(const uint8_t *d_src, uint8_t *d_dst, int B, int Hs, int Ws, int Hd, int Wd,
+                    int resize_mode, int pad_value, void *stream);
 
 /* ---------------------------------------------------------------- K2 YOLOv3 grid/anchor decode
  * Replaces YoloV3Layer.forward, eval branch (networks/modules/heads/detection/yolov3.py:263-304;
@@ -163,6 +171,18 @@ int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_th
  * (image order), *d_total (optional) = number of rows written.  d_dst holds >= B*capacity*D floats. */
 int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D,
                  float *d_dst, int32_t *d_total, void *stream);
+
+/* ---------------------------------------------------------------- result formatting
+ * vx_pack_rows + the output_format column slicing of get_prediction_results (predictor/utils.py:11-33) /
+ * BaseRuntime.__call__ (src/runtime/vortex/runtime/basic_runtime.py:103-111) + the relative->absolute
+ * scaling of InferenceHelper.adjust_coordinates (src/runtime/vortex/runtime/helper.py:292-307), one launch:
+ *   d_dst f32[sum_b n_b, n_cols], row-major, images back to back; column j = d_src column h_cols[j],
+ *   multiplied (fp32) by d_image_wh[b][0] when h_kinds[j]==1 (x), by d_image_wh[b][1] when ==2 (y).
+ * h_cols i32[n_cols] / h_kinds u8[n_cols] are HOST arrays (read during the call); h_kinds or d_image_wh
+ * NULL = no scaling.  n_cols <= VX_MAX_FORMAT_COLS, D <= 256. */
+int vx_format_results(const float *d_src, const int32_t *d_counts, int B, int capacity, int D,
+                      const int32_t *h_cols, const uint8_t *h_kinds, int n_cols,
+                      const float *d_image_wh, float *d_dst, int32_t *d_total, void *stream);
 
 /* ---------------------------------------------------------------- measurement hooks (no reference
  * counterpart; bench.py's roofline leg).  When enabled, every kernel family launched by this library is

@@ -329,9 +329,11 @@ def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int, letterbox: bool 
         return out
 
     def taps(n_out, n_in):
-        scale = np.float32(n_in) / np.float32(n_out)
-        d = np.arange(n_out, dtype=np.float32)
-        f = (d + np.float32(0.5)) * scale - np.float32(0.5)
+        # OpenCV resize(): inv_scale = (double)dsize/ssize, scale = 1./inv_scale; fx = (float)((dx+0.5)*scale-0.5);
+        # sx = cvFloor(fx); fx -= sx; border clamps zero fx; the two weights are rounded separately:
+        # saturate_cast<short>({1.f-fx, fx} * 2048) (round half to even).
+        scale = np.float64(1.0) / (np.float64(n_out) / np.float64(n_in))
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
         i0 = np.floor(f).astype(np.int32)
         fr = (f - i0.astype(np.float32)).astype(np.float32)
         lo = i0 < 0
@@ -339,8 +341,8 @@ def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int, letterbox: bool 
         hi = i0 >= n_in - 1
         i0 = np.where(hi, n_in - 1, i0); fr = np.where(hi, np.float32(0), fr)
         i1 = np.minimum(i0 + 1, n_in - 1)
+        w0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int32)
         w1 = np.rint(fr * np.float32(2048)).astype(np.int32)
-        w0 = 2048 - w1
         return i0, i1, w0, w1
 
     x0, x1, a0, a1 = taps(out_w, W)
@@ -354,11 +356,17 @@ def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int, letterbox: bool 
 
 def resize_batch(images: Sequence[np.ndarray], size: Tuple[int, int, int, int],
                  letterbox: bool = False) -> np.ndarray:
-    """src/runtime/vortex/runtime/basic_runtime.py:75-90: resize each image to (h,w),
-    pad the batch with zero images up to n, stack to u8[n,h,w,c]."""
+    """src/runtime/vortex/runtime/basic_runtime.py:75-90: resize each image, pad the batch with zero
+    images up to n, stack.  Quirk kept: the reference hands (h,w) to cv2.resize, whose
+    dsize is (width,height), so a resized image has w rows and h columns -- identical for the square
+    inputs every shipped config uses; for h != w the stack with (h,w,c) pad images raises ValueError
+    exactly as np.stack does there.  letterbox (build extension) resizes to (h,w) proper."""
     assert len(size) == 4
     n, h, w, c = size if size[-1] == 3 else tuple(size[i] for i in [0, 3, 1, 2])
-    out = [resize_bilinear_u8(im, h, w, letterbox) for im in images]
+    if letterbox:
+        out = [resize_bilinear_u8(im, h, w, True) for im in images]
+    else:
+        out = [resize_bilinear_u8(im, w, h) for im in images]
     out += [np.zeros((h, w, c), dtype=images[0].dtype)] * (n - len(images))
     return np.stack(out)
 
@@ -379,6 +387,22 @@ def get_prediction_results(results, output_format):
             d[k] = np.take(r, indices=ind, axis=output_format[k]["axis"]) if all(r.shape) else None
         final.append(d)
     return final
+
+
+def adjust_coordinates(batch_vis, batch_results, coordinate_fmt="relative"):
+    """InferenceHelper.adjust_coordinates (src/runtime/vortex/runtime/helper.py:277-310): in-place scaling
+    of bounding_box / landmarks x by im_w and y by im_h when the coordinates are 'relative'."""
+    assert coordinate_fmt in ["relative", "absolute"]
+    if coordinate_fmt != "relative":
+        return batch_results
+    for vis, result in zip(batch_vis, batch_results):
+        im_h, im_w, _ = vis.shape
+        for key in ("bounding_box", "landmarks"):
+            if key in result and result[key] is not None:
+                a = result[key]
+                a[..., 0::2] *= im_w
+                a[..., 1::2] *= im_h
+    return batch_results
 
 
 # --------------------------------------------------------------------------- §8f-1 DETR

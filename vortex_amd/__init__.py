@@ -10,9 +10,10 @@ reference's own nn.Module API for that path:
     prior.PriorBoxDecoder / PriorBoxPostProcess
     predictor.BasePredictor / create_predictor / get_prediction_results
     detr.DETRPostProcess
+    runtime.resize_batch / format_detections / adjust_coordinates / InferenceHelper
     parallel.shard_batch / allgather_detections
 """
-from . import _lib, ops  # noqa: F401
+from . import _lib, ops, runtime  # noqa: F401
 from .preprocess import Normalize, FlipNormalize, get_preprocess  # noqa: F401
 from .heads import YoloV3Layer, yolo_feature_maps  # noqa: F401
 from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostProcess,  # noqa: F401

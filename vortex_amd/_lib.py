@@ -28,6 +28,7 @@ _SIGNATURES = {
     "vx_error_string": (ctypes.c_char_p, [c_int]),
     "vx_preprocess_u8hwc_f32nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             _F3, _F3, c_int, c_int, c_int, c_int, c_void_p]),
+    "vx_resize_u8hwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vx_yolo_head_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _F6, c_float,
                                     c_int64, c_int64, c_void_p]),
     "vx_yolo_decode_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -48,6 +49,8 @@ _SIGNATURES = {
                                c_void_p, c_size_t, c_void_p]),
     "vx_detr_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vx_format_results": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32),
+                                  ctypes.POINTER(ctypes.c_uint8), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vx_profile_enable": (c_int, [c_int]),
     "vx_profile_select": (c_int, [ctypes.c_uint]),
     "vx_profile_disable": (c_int, []),

@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256) void vx_k_normalize_scalar(const uint8_t *__re
 // (nh,nw) and centred; outside pixels take lut[pad_value].
 struct vx_resize_params { int Hs, Ws, Hd, Wd; int nh, nw, top, left; int pad; };
 
+// OpenCV computes the source coordinate in double and narrows to float, then rounds the two weights
+// separately: cbuf = {1.f - fx, fx}, saturate_cast<short>(cbuf[k] * 2048)  (round half to even).
 __device__ __forceinline__ void vx_tap(int d, int n_out, int n_in, int &i0, int &i1, int &w0, int &w1) {
-    float scale = (float)n_in / (float)n_out;
-    float f = ((float)d + 0.5f) * scale - 0.5f;
+    double scale = 1.0 / ((double)n_out / (double)n_in);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
     float fl = floorf(f);
     int i = (int)fl;
     float fr = f - fl;
@@ -119,8 +121,50 @@ __device__ __forceinline__ void vx_tap(int d, int n_out, int n_in, int &i0, int 
     if (i >= n_in - 1) { i = n_in - 1; fr = 0.0f; }
     i0 = i;
     i1 = min(i + 1, n_in - 1);
+    w0 = (int)rintf((1.0f - fr) * 2048.0f);
     w1 = (int)rintf(fr * 2048.0f);
-    w0 = 2048 - w1;
+}
+
+// One output pixel (3 channels) of the resized / letterboxed image b.
+__device__ __forceinline__ void vx_resize_pixel(const uint8_t *__restrict__ src, const vx_resize_params &r, int b,
+                                                int y, int x, int &v0, int &v1, int &v2) {
+    int yy = y - r.top, xx = x - r.left;
+    if (yy < 0 || yy >= r.nh || xx < 0 || xx >= r.nw) {
+        v0 = v1 = v2 = r.pad;
+        return;
+    }
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    vx_tap(xx, r.nw, r.Ws, x0, x1, a0, a1);
+    vx_tap(yy, r.nh, r.Hs, y0, y1, b0, b1);
+    const uint8_t *s = src + (long long)b * r.Hs * r.Ws * 3;
+    const uint8_t *r0 = s + ((long long)y0 * r.Ws) * 3;
+    const uint8_t *r1 = s + ((long long)y1 * r.Ws) * 3;
+    int out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out[c] = min(max(v, 0), 255);
+    }
+    v0 = out[0]; v1 = out[1]; v2 = out[2];
+}
+
+// resize only: u8 HWC -> u8 HWC (BaseRuntime.resize_batch, basic_runtime.py:75-90)
+__global__ __launch_bounds__(256) void vx_k_resize_u8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                      int B, vx_resize_params r) {
+    const long long HWd = (long long)r.Hd * r.Wd;
+    const long long total = HWd * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / HWd);
+        int pp = (int)(i - (long long)b * HWd);
+        int y = pp / r.Wd, x = pp - y * r.Wd;
+        int v0, v1, v2;
+        vx_resize_pixel(src, r, b, y, x, v0, v1, v2);
+        uint8_t *d = dst + i * 3;
+        d[0] = (uint8_t)v0; d[1] = (uint8_t)v1; d[2] = (uint8_t)v2;
+    }
 }
 
 __global__ __launch_bounds__(256) void vx_k_resize_normalize(const uint8_t *__restrict__ src,
@@ -136,27 +180,8 @@ __global__ __launch_bounds__(256) void vx_k_resize_normalize(const uint8_t *__re
         int b = (int)(i / HWd);
         int pp = (int)(i - (long long)b * HWd);
         int y = pp / r.Wd, x = pp - y * r.Wd;
-        int yy = y - r.top, xx = x - r.left;
         int v0, v1, v2;
-        if (yy < 0 || yy >= r.nh || xx < 0 || xx >= r.nw) {
-            v0 = v1 = v2 = r.pad;
-        } else {
-            int x0, x1, a0, a1, y0, y1, b0, b1;
-            vx_tap(xx, r.nw, r.Ws, x0, x1, a0, a1);
-            vx_tap(yy, r.nh, r.Hs, y0, y1, b0, b1);
-            const uint8_t *s = src + (long long)b * r.Hs * r.Ws * 3;
-            const uint8_t *r0 = s + ((long long)y0 * r.Ws) * 3;
-            const uint8_t *r1 = s + ((long long)y1 * r.Ws) * 3;
-            int out[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
-                int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
-                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                out[c] = min(max(v, 0), 255);
-            }
-            v0 = out[0]; v1 = out[1]; v2 = out[2];
-        }
+        vx_resize_pixel(src, r, b, y, x, v0, v1, v2);
         int c0 = s0 == 0 ? v0 : v2, c2 = s2 == 2 ? v2 : v0;
         float *d = dst + (long long)b * 3 * HWd + pp;
         d[0] = lut[c0];
@@ -170,6 +195,35 @@ static inline int vx_grid_for(long long work_items, int block, int max_blocks) {
     if (g > max_blocks) g = max_blocks;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+static vx_resize_params vx_make_resize(int Hs, int Ws, int Hd, int Wd, int resize_mode, int pad_value) {
+    vx_resize_params r;
+    r.Hs = Hs; r.Ws = Ws; r.Hd = Hd; r.Wd = Wd; r.pad = pad_value;
+    if (resize_mode == VX_RESIZE_LETTERBOX) {
+        double sc = (double)Hd / Hs < (double)Wd / Ws ? (double)Hd / Hs : (double)Wd / Ws;
+        // python round(): half to even, matches the oracle's int(round(.))
+        r.nh = (int)__builtin_rint(Hs * sc); if (r.nh < 1) r.nh = 1;
+        r.nw = (int)__builtin_rint(Ws * sc); if (r.nw < 1) r.nw = 1;
+        r.top = (Hd - r.nh) / 2; r.left = (Wd - r.nw) / 2;
+    } else {
+        r.nh = Hd; r.nw = Wd; r.top = 0; r.left = 0;
+    }
+    return r;
+}
+
+extern "C" int vx_resize_u8hwc(const uint8_t *d_src, uint8_t *d_dst, int B, int Hs, int Ws, int Hd, int Wd,
+                               int resize_mode, int pad_value, void *stream) {
+    if (!d_src || !d_dst || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return VX_ERR_INVALID_ARG;
+    if (resize_mode != VX_RESIZE_STRETCH && resize_mode != VX_RESIZE_LETTERBOX) return VX_ERR_INVALID_ARG;
+    if (pad_value < 0 || pad_value > 255) return VX_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
+    long long total = (long long)Hd * Wd * B;
+    vx_prof_begin(VX_PROF_PREPROCESS, st);
+    hipLaunchKernelGGL(vx_k_resize_u8, dim3(vx_grid_for(total, 256, 256 * 8)), dim3(256), 0, st, d_src, d_dst, B, r);
+    vx_prof_end(VX_PROF_PREPROCESS, st);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
 
 extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, int B, int Hs, int Ws,
@@ -202,17 +256,7 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
                                d_src, d_dst, HW, total, p);
         }
     } else {
-        vx_resize_params r;
-        r.Hs = Hs; r.Ws = Ws; r.Hd = Hd; r.Wd = Wd; r.pad = pad_value;
-        if (resize_mode == VX_RESIZE_LETTERBOX) {
-            double sc = (double)Hd / Hs < (double)Wd / Ws ? (double)Hd / Hs : (double)Wd / Ws;
-            // python round(): half to even, matches the oracle's int(round(.))
-            r.nh = (int)__builtin_rint(Hs * sc); if (r.nh < 1) r.nh = 1;
-            r.nw = (int)__builtin_rint(Ws * sc); if (r.nw < 1) r.nw = 1;
-            r.top = (Hd - r.nh) / 2; r.left = (Wd - r.nw) / 2;
-        } else {
-            r.nh = Hd; r.nw = Wd; r.top = 0; r.left = 0;
-        }
+        vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
         long long total = (long long)Hd * Wd * B;
         hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
                            d_src, d_dst, B, r, p);

@@ -42,6 +42,45 @@ def preprocess(img: torch.Tensor, mean: Sequence[float], std: Sequence[float], s
     return out
 
 
+def resize_u8(img: torch.Tensor, out_size: Tuple[int, int], letterbox: bool = False, pad_value: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """u8[B,Hs,Ws,3] -> u8[B,Hd,Wd,3] (cv2.resize INTER_LINEAR scheme); see vx_resize_u8hwc."""
+    L.require_cuda(img, "input")
+    assert img.dtype == torch.uint8 and img.dim() == 4 and img.size(3) == 3
+    img = img.contiguous()
+    B, Hs, Ws, _ = img.shape
+    Hd, Wd = int(out_size[0]), int(out_size[1])
+    if out is None:
+        out = torch.empty((B, Hd, Wd, 3), dtype=torch.uint8, device=img.device)
+    assert out.is_contiguous() and tuple(out.shape) == (B, Hd, Wd, 3) and out.dtype == torch.uint8
+    rc = L.lib().vx_resize_u8hwc(img.data_ptr(), out.data_ptr(), B, Hs, Ws, Hd, Wd,
+                                 L.VX_RESIZE_LETTERBOX if letterbox else L.VX_RESIZE_STRETCH, int(pad_value),
+                                 L.stream_ptr(img.device))
+    L.check(rc, "vx_resize_u8hwc")
+    return out
+
+
+def format_results(out_det: torch.Tensor, keep_counts: torch.Tensor, cols: Sequence[int],
+                   kinds: Optional[Sequence[int]] = None, image_wh: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32[B,cap,D] + i32[B] -> f32[B*cap, len(cols)]: kept rows of all images back to back, columns
+    gathered by `cols`, kind 1/2 columns scaled by image_wh[b] = (w,h); see vx_format_results."""
+    import ctypes
+    L.require_cuda(out_det, "detections")
+    B, cap, D = out_det.shape
+    n = len(cols)
+    dst = torch.empty((B * cap, n), dtype=torch.float32, device=out_det.device)
+    c_cols = (ctypes.c_int32 * n)(*[int(c) for c in cols])
+    c_kinds = (ctypes.c_uint8 * n)(*[int(k) for k in kinds]) if kinds is not None else None
+    if image_wh is not None:
+        L.require_cuda(image_wh, "image_wh")
+        assert image_wh.dtype == torch.float32 and tuple(image_wh.shape) == (B, 2) and image_wh.is_contiguous()
+    rc = L.lib().vx_format_results(out_det.data_ptr(), keep_counts.data_ptr(), B, cap, D, c_cols, c_kinds, n,
+                                   image_wh.data_ptr() if image_wh is not None else None, dst.data_ptr(), None,
+                                   L.stream_ptr(out_det.device))
+    L.check(rc, "vx_format_results")
+    return dst
+
+
 # --------------------------------------------------------------------------------------- K2
 def yolo_head_decode(x: torch.Tensor, anchor_wh: Sequence[float], stride: float,
                      out: Optional[torch.Tensor] = None, row_offset: int = 0) -> torch.Tensor:

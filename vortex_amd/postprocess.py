@@ -166,9 +166,15 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
     def forward_device(self, input, score_threshold, iou_threshold):
         """No host sync: returns (packed f32[B*cap,D] = kept rows of all images back to back,
         meta i32[2B+1] = counts|keep_counts|status)."""
+        out_det, keep_counts, meta = self.forward_unpacked(input, score_threshold, iou_threshold)
+        return ops.pack_rows(out_det, keep_counts), meta
+
+    def forward_unpacked(self, input, score_threshold, iou_threshold):
+        """No host sync, no packing: (out_det f32[B,cap,D], keep_counts i32[B], meta) -- the input of
+        runtime.format_detections (on-device output_format slicing)."""
         c = self.decoder.decode_batch(input, score_threshold)
         _, out_det, keep_counts, _ = ops.candidates_nms(c, _f(iou_threshold), self.n_classes_hint(input), self.top_k)
-        return ops.pack_rows(out_det, keep_counts), c.meta
+        return out_det, keep_counts, c.meta
 
     def forward_async(self, input, score_threshold, iou_threshold) -> "PendingDetections":
         """Enqueue the whole post-process plus the D2H copy of the counts and return at once; the
