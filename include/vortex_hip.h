@@ -43,6 +43,14 @@ extern "C" {
 
 #define VX_MAX_FORMAT_COLS    64    /* columns of one formatted result row                */
 
+/* use_threshold argument of the decoders: bit 0 = apply the score threshold.  vx_yolo_fused_decode also takes
+ * bit 1 = "threshold first": read the objectness plane first and the box/class planes only where a row
+ * survives.  Same outputs bit for bit; HBM traffic falls from (5+C) planes to 1 plane + the sectors of the
+ * survivors.  Deviation (why it is opt-in): the reference's NaN check (postprocess/yolov3.py:35-36) then
+ * covers every objectness value but the box/class values of surviving lanes only. */
+#define VX_DECODE_THRESHOLD       1
+#define VX_DECODE_THRESHOLD_FIRST 2
+
 #define VX_RESIZE_STRETCH     0     /* src/runtime/vortex/runtime/basic_runtime.py:66-68 */
 #define VX_RESIZE_LETTERBOX   1     /* build-side extension (basic_runtime.py:70-73 is a TODO) */
 

@@ -279,6 +279,15 @@ def test_fused_equals_unfused_and_oracle(sthr, ithr):
     unfused = V.YoloV3PostProcess(img_size=S)(out, torch.tensor([sthr]), torch.tensor([ithr]))
     for f, u in zip(fused, unfused):
         same(f, u)
+    # threshold-first decode (objectness plane first, other planes for surviving lanes only): same bits
+    tf = V.YoloV3FusedPostProcess(img_size=S, nan_check="survivors")(dheads, torch.tensor([sthr]), torch.tensor([ithr]))
+    for f, t in zip(fused, tf):
+        same(f, t)
+    c0, c1 = ops.yolo_fused_decode(dheads, S, sthr), ops.yolo_fused_decode(dheads, S, sthr, threshold_first=True)
+    same(c0.meta, c1.meta)
+    for b, k in enumerate(c0.counts.cpu().tolist()):
+        same(c0.boxes[b, :k], c1.boxes[b, :k]); same(c0.scores[b, :k], c1.scores[b, :k])
+        same(c0.cls[b, :k], c1.cls[b, :k]); same(c0.det[b, :k], c1.det[b, :k])
     # candidates vs oracle
     pred = O.yolo_head_eval(heads, S)
     assert float((pred[..., 4] - sthr).abs().min()) > 1e-6     # no borderline objectness in this seed
@@ -316,6 +325,42 @@ def test_prior_decode_and_postprocess(L, NL, P, B, sthr):
         keep = O.batched_nms(gb, gs, gc, torch.tensor([0.4]))
         same(res[b], c.det[b, :k].cpu()[keep])
         assert res[b].shape[1] == 6 + 2 * L
+
+
+def test_fused_nan_check_modes():
+    """nan_check="full" == reference (ValueError for a NaN anywhere, postprocess/yolov3.py:35-36);
+    "survivors": NaN objectness anywhere or NaN in a surviving row still raises, a NaN class logit of a
+    row that fails the threshold is not read (documented deviation of the opt-in mode)."""
+    S, C, B = 416, 80, 2
+    heads = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=43)]
+    st, it = torch.tensor([0.9]), torch.tensor([0.2])
+    full, sparse = V.YoloV3FusedPostProcess(S), V.YoloV3FusedPostProcess(S, nan_check="survivors")
+    ref = full(heads, st, it)
+    G = heads[2].shape[-1]
+    obj = heads[2].view(B, 3, 5 + C, G, G)[:, :, 4]
+    # a cell below the threshold whose 4-cell lane group (16-B load granule) has no survivor either
+    quiet = (obj.reshape(B, 3, G * G // 4, 4) < 0).all(-1).nonzero()[0].tolist()
+    dead = [quiet[0], quiet[1], (quiet[2] * 4) // G, (quiet[2] * 4) % G]
+    hot = (torch.sigmoid(obj) > 0.9).nonzero()[0].tolist()    # a surviving cell
+
+    def poke(cell, ch):
+        hs = [h.clone() for h in heads]
+        b, a, y, x = cell
+        hs[2].view(B, 3, 5 + C, G, G)[b, a, ch, y, x] = float("nan")
+        return hs
+
+    for ch in (4, 0, 5 + 17):                                 # NaN objectness / box / class of a surviving row
+        for pp in (full, sparse):
+            with pytest.raises(ValueError):
+                pp(poke(hot, ch), st, it)
+    for pp in (full, sparse):                                 # NaN objectness of any row
+        with pytest.raises(ValueError):
+            pp(poke(dead, 4), st, it)
+    with pytest.raises(ValueError):
+        full(poke(dead, 5 + 17), st, it)
+    got = sparse(poke(dead, 5 + 17), st, it)                  # not read: results unchanged
+    for g, r in zip(got, ref):
+        same(g, r)
 
 
 # ------------------------------------------------------------------------------------------- DETR (§8f-1)

@@ -134,6 +134,7 @@ struct vx_rows_params {
     int B, R, C, NP, tiles_per_img;
     float img_size, thr;
     int use_thr;
+    int sparse_max;     // threshold-first: tiles with more survivors than this are streamed
 };
 
 __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__restrict__ pred,
@@ -229,6 +230,7 @@ struct vx_fused_params {
     int B, C, NP, R, tiles_per_img;
     float img_size, thr;
     int use_thr;
+    int sparse_max;     // threshold-first: tiles with more survivors than this are streamed
 };
 
 __device__ __forceinline__ int vx_fused_tile_row0(const vx_fused_params &p, int t, int &si, int &a, int &cell0) {
@@ -358,7 +360,86 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
     if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
 }
 
-template <int UN, bool NT>
+// "Threshold first" tile: the objectness plane is read first (coalesced, 1/(5+C) of the bytes); a tile with
+// no survivor is finished.  For each survivor the WAVE gathers the cell's 5+C channel values in one round trip
+// (lane = channel, stride = one plane), reduces (max sigmoid, first index) by butterfly and the owner lane
+// writes the record -- same arithmetic and same bits as the streaming tile.  HBM traffic: 1 plane + (5+C)
+// 128-B lines per survivor; tiles with more than p.sparse_max survivors (a quarter of it for 64-cell tiles)
+// return false and are streamed.
+// The NaN test covers every objectness value but the box/class values of surviving rows only (opt-in mode).
+template <int V>
+__device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, const vx_scale_desc &s, int b, int a,
+                                                     int cell0, int row0, int tile, vx_rec *stage, int *tile_counts,
+                                                     int *status) {
+    const int lane = vx_lane();
+    const int c0 = cell0 + lane * V;
+    const bool live = c0 < s.cells;
+    const long long cells = s.cells;
+    const float *base = s.ptr + ((long long)(b * 3 + a) * p.NP) * cells;      // channel 0, cell 0 of this plane set
+    vx_cells<V> to;
+#pragma unroll
+    for (int j = 0; j < V; ++j) to.v[j] = 0.f;
+    if (live) to = vx_load_cells<V, false>(base + 4 * cells + c0);
+    bool nan = false;
+    float obj[V];
+    bool pass[V];
+    u64 m[V];
+    int below = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        nan |= (to.v[j] != to.v[j]);
+        obj[j] = live ? vx_sigmoid(to.v[j]) : 0.f;
+        pass[j] = live && (obj[j] > p.thr);
+        m[j] = __ballot(pass[j]);
+        below += vx_mbcnt(m[j]);
+        total += __popcll(m[j]);
+    }
+    if (total > (V == 4 ? p.sparse_max : (p.sparse_max + 3) / 4)) return false;   // wave-uniform
+    int mypos = below;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        u64 mj = m[j];
+        while (mj) {                                                          // wave-uniform loop over survivors
+            const int L = __ffsll((long long)mj) - 1;
+            mj &= mj - 1;
+            const float *q = base + (cell0 + L * V + j);
+            float best = -INFINITY, v0 = 0.f;
+            int bi = 0x7fffffff;
+            for (int ch = lane; ch < p.NP; ch += VX_WAVE) {
+                float v = q[(long long)ch * cells];
+                nan |= (v != v);
+                if (ch < VX_WAVE) v0 = v;
+                if (ch >= 5) {
+                    float sg = vx_sigmoid(v);
+                    if (sg > best) { best = sg; bi = ch - 5; }                // ascending ch within a lane: first max
+                }
+            }
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) {
+                float ob = __shfl_xor(best, k, VX_WAVE);
+                int oi = __shfl_xor(bi, k, VX_WAVE);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            float tx = __shfl(v0, 0, VX_WAVE), ty = __shfl(v0, 1, VX_WAVE);
+            float tw = __shfl(v0, 2, VX_WAVE), th = __shfl(v0, 3, VX_WAVE);
+            if (lane == L) {
+                int gc = c0 + j;
+                float cx = vx_yolo_xy(tx, (float)(gc % s.G), s.stride);
+                float cy = vx_yolo_xy(ty, (float)(gc / s.G), s.stride);
+                float w = vx_yolo_wh(tw, s.aw[a], s.stride);
+                float h = vx_yolo_wh(th, s.ah[a], s.stride);
+                stage[(long long)b * p.R + row0 + mypos] =
+                    vx_yolo_record(cx, cy, w, h, obj[j], best, bi, row0 + lane * V + j, p.img_size);
+            }
+        }
+        if (pass[j]) ++mypos;
+    }
+    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
+    return true;
+}
+
+template <int UN, bool NT, bool SPARSE>
 __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
                                                        int *__restrict__ tile_counts, int *__restrict__ status) {
     long long wtile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -369,6 +450,11 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec
     int si, a, cell0;
     int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
     const vx_scale_desc &s = p.s[si];                 // wave-uniform
+    if constexpr (SPARSE) {
+        if (s.vec ? vx_fused_tile_sparse<4>(p, s, b, a, cell0, row0, t, stage, tile_counts, status)
+                  : vx_fused_tile_sparse<1>(p, s, b, a, cell0, row0, t, stage, tile_counts, status))
+            return;
+    }
     if (s.vec) vx_fused_tile<4, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
     else vx_fused_tile<1, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
 }
@@ -582,7 +668,12 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     int rc = vx_fused_setup(p, d_head0, d_head1, d_head2, B, S, C, anchors_px);
     if (rc != VX_OK) return rc;
     if (p.R > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
-    p.img_size = (float)S; p.thr = score_threshold; p.use_thr = use_threshold ? 1 : 0;
+    p.img_size = (float)S; p.thr = score_threshold; p.use_thr = (use_threshold & 1) ? 1 : 0;
+    const bool sparse = p.use_thr && (use_threshold & VX_DECODE_THRESHOLD_FIRST);
+    // A/B on MI355X, B=256 (tools/ab_fused.py; streaming = 0.150-0.177 ms at every threshold): 8 -> 0.015 / 0.046 /
+    // 0.118 / 0.158 / 0.167 / 0.176 ms at thr 0.9 / 0.7 / 0.5 / 0.3 / 0.2 / 0.06; 16 and 32 lose up to 2.3x at 0.2-0.3;
+    // 3 lets a rare streamed tile (one ~38 us dependent chain) set the floor of the sparse case.
+    p.sparse_max = 8;
     if (workspace_bytes < vx_stage_bytes(B, p.R, vx_fused_tiles(S), 0)) return VX_ERR_WORKSPACE;
     vx_rec *stage = (vx_rec *)d_workspace;
     int *tile_counts = (int *)((char *)d_workspace + vx_align256((size_t)B * p.R * sizeof(vx_rec)));
@@ -593,8 +684,12 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     vx_prof_begin(VX_PROF_FUSED, st);
     // <2, true>: 2 channel planes per register batch in ping-pong (7 waves/SIMD), non-temporal loads.
     // A/B on MI355X, B=256 (tools/ab_fused.py): UN 8/4/3/2/1 with nt = 5.0/5.9/5.9/6.19/5.96 TB/s, UN 4/2 plain = 5.5/5.67.
-    hipLaunchKernelGGL((vx_k_yolo_fused<2, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage, tile_counts,
-                       d_status);
+    if (sparse)
+        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
+                           tile_counts, d_status);
+    else
+        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
+                           tile_counts, d_status);
     vx_prof_end(VX_PROF_FUSED, st);
     vx_finish_params f;
     f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;

@@ -145,8 +145,10 @@ def yolo_decode(pred: torch.Tensor, img_size: float, score_threshold: float, use
 
 # --------------------------------------------------------------------------------------- K2+K3 fused
 def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float,
-                      use_threshold: bool = True, anchors=COCO_ANCHORS) -> Candidates:
-    """heads: raw conv outputs for G = S/32, S/16, S/8 (coarse -> fine)."""
+                      use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False) -> Candidates:
+    """heads: raw conv outputs for G = S/32, S/16, S/8 (coarse -> fine).  threshold_first: read the objectness
+    planes first and the other planes only for surviving rows (VX_DECODE_THRESHOLD_FIRST; same outputs, the NaN
+    check then covers objectness everywhere but box/class values of surviving lanes only)."""
     assert len(heads) == 3
     hs = []
     for h, d in zip(heads, (32, 16, 8)):
@@ -161,7 +163,8 @@ def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_thresh
     ws = _ws(nb, hs[0].device)
     flat = [float(v) for a in anchors for v in a]
     rc = L.lib().vx_yolo_fused_decode(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C,
-                                      L.f18(flat), float(score_threshold), int(bool(use_threshold)),
+                                      L.f18(flat), float(score_threshold),
+                                      int(bool(use_threshold)) | (2 if threshold_first else 0),
                                       c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(), c.det.data_ptr(),
                                       c.counts.data_ptr(), c.status.data_ptr(), ws.data_ptr(), nb,
                                       L.stream_ptr(hs[0].device))

@@ -235,20 +235,26 @@ class YoloV3PostProcess(BatchedNMSPostProcess):
 
 
 class _FusedYoloDecoder(nn.Module):
-    def __init__(self, img_size, threshold=True, anchors=ops.COCO_ANCHORS):
+    def __init__(self, img_size, threshold=True, anchors=ops.COCO_ANCHORS, nan_check="full"):
         super().__init__()
-        self.img_size, self.threshold, self.anchors = img_size, threshold, anchors
+        assert nan_check in ("full", "survivors")
+        self.img_size, self.threshold, self.anchors, self.nan_check = img_size, threshold, anchors, nan_check
 
     def decode_batch(self, input: Sequence[torch.Tensor], score_threshold) -> ops.Candidates:
-        return ops.yolo_fused_decode(input, int(self.img_size), _f(score_threshold), self.threshold, self.anchors)
+        return ops.yolo_fused_decode(input, int(self.img_size), _f(score_threshold), self.threshold, self.anchors,
+                                     threshold_first=(self.nan_check == "survivors"))
 
 
 class YoloV3FusedPostProcess(BatchedNMSPostProcess):
     """Build-side extension: YoloV3Layer x3 + concat + YoloV3Decoder + BatchedNMS from the three RAW head
     tensors (coarse -> fine: G = S/32, S/16, S/8), bit-identical to YoloV3Layer -> YoloV3PostProcess."""
 
-    def __init__(self, img_size, threshold: bool = True, anchors=ops.COCO_ANCHORS, top_k: Optional[int] = None):
-        super().__init__(decoder=_FusedYoloDecoder(img_size, threshold, anchors), nms=True, top_k=top_k)
+    def __init__(self, img_size, threshold: bool = True, anchors=ops.COCO_ANCHORS, top_k: Optional[int] = None,
+                 nan_check: str = "full"):
+        """nan_check="full": the reference's ValueError for a NaN anywhere in the prediction (every byte of the
+        heads is read).  "survivors": threshold-first decode -- identical detections, but only objectness values
+        and the rows that pass the threshold are NaN-checked, and only those are read from HBM."""
+        super().__init__(decoder=_FusedYoloDecoder(img_size, threshold, anchors, nan_check), nms=True, top_k=top_k)
 
     def n_classes_hint(self, input) -> int:
         return int(input[0].size(1)) // 3 - 5
