@@ -169,7 +169,7 @@ def main():
             pre_done = s_pre.record_event()
         with torch.cuda.stream(s_post):
             _, out_det, keep_counts, _ = ops.candidates_nms(c, args.iou_thr, C, None)
-            pend = V.postprocess.PendingDetections(ops.pack_rows(out_det, keep_counts), c.meta)
+            pend = V.postprocess.PendingDetections.packing(out_det, keep_counts, c.meta)
             s_post.wait_event(pre_done)                                     # next decode starts after K1
         return x, pend if args.depth > 1 else pend.result()
 
@@ -177,17 +177,16 @@ def main():
         if two_streams:
             return step_two_streams()
         x = norm(img)                                       # K1 (consumed by the backbone, out of scope)
+        inp = heads
         if args.unfused:
             for (layer, off), h in zip(layers, heads):
                 layer(h, out=decoded, row_offset=off)
-            packed, meta = post.forward_device(decoded, sthr, ithr)
-        else:
-            packed, meta = post.forward_device(heads, sthr, ithr)
+            inp = decoded
         if args.allgather:
+            packed, meta = post.forward_device(inp, sthr, ithr)
             return x, parallel.allgather_detections(packed, meta, B)
-        if args.depth > 1:
-            return x, V.postprocess.PendingDetections(packed, meta)   # D2H of the counts enqueued, not awaited
-        return x, V.postprocess.finish_results(packed, meta)   # the path's one D2H sync + tuple
+        pend = post.forward_async(inp, sthr, ithr)          # counts land in pinned host memory, not awaited
+        return x, pend if args.depth > 1 else pend.result()
 
     def run_steps(n):
         """n full steps; every step's per-image tuple is materialised before this returns."""

@@ -176,9 +176,13 @@ int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_th
 /* ---------------------------------------------------------------- tuple packing
  * The `tuple(results)` of BatchedNMSPostProcess.forward (base_postprocess.py:131-138) as one launch:
  * rows [0, min(d_counts[b],capacity)) of d_src f32[B,capacity,D] are copied back to back into d_dst
- * (image order), *d_total (optional) = number of rows written.  d_dst holds >= B*capacity*D floats. */
+ * (image order), *d_total (optional) = number of rows written.  d_dst holds >= B*capacity*D floats.
+ * meta_dst (optional): n_meta int32 words are copied from d_meta_src (the counts|keep_counts|status words of
+ * the call chain) to meta_dst, which may be PINNED HOST memory mapped into the device (plain stores, visible
+ * to the host once an event recorded after this call has completed) -- the path then needs no D2H memcpy. */
 int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D,
-                 float *d_dst, int32_t *d_total, void *stream);
+                 float *d_dst, int32_t *d_total,
+                 const int32_t *d_meta_src, int32_t *meta_dst, int n_meta, void *stream);
 
 /* ---------------------------------------------------------------- result formatting
  * vx_pack_rows + the output_format column slicing of get_prediction_results (predictor/utils.py:11-33) /

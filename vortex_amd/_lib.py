@@ -48,7 +48,8 @@ _SIGNATURES = {
                                c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
     "vx_detr_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
-    "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_int, c_void_p]),
     "vx_format_results": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32),
                                   ctypes.POINTER(ctypes.c_uint8), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vx_profile_enable": (c_int, [c_int]),

@@ -843,9 +843,14 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
 // rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
 __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ src, const int *__restrict__ counts,
                                                       int B, int cap, int D, float *__restrict__ dst,
-                                                      int *__restrict__ total) {
+                                                      int *__restrict__ total, const int *__restrict__ meta_src,
+                                                      int *__restrict__ meta_dst, int n_meta) {
     __shared__ int s_part[256];
     const int b = blockIdx.x;
+    // the counts / status words of the call chain, mirrored for the host (meta_dst may be pinned host memory:
+    // plain stores, visible after the stream's next event) so the path needs no D2H memcpy
+    if (b == 0 && meta_dst)
+        for (int i = threadIdx.x; i < n_meta; i += 256) meta_dst[i] = meta_src[i];
     int acc = 0;
     for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
     s_part[threadIdx.x] = acc;
@@ -863,12 +868,14 @@ __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ 
 }
 
 extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D, float *d_dst,
-                            int32_t *d_total, void *stream) {
+                            int32_t *d_total, const int32_t *d_meta_src, int32_t *meta_dst, int n_meta, void *stream) {
     if (!d_src || !d_counts || !d_dst) return VX_ERR_INVALID_ARG;
     if (B <= 0 || capacity <= 0 || D <= 0) return VX_ERR_INVALID_ARG;
+    if (meta_dst && (!d_meta_src || n_meta <= 0)) return VX_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_PACK, st);
-    hipLaunchKernelGGL(vx_k_pack_rows, dim3(B), dim3(256), 0, st, d_src, d_counts, B, capacity, D, d_dst, d_total);
+    hipLaunchKernelGGL(vx_k_pack_rows, dim3(B), dim3(256), 0, st, d_src, d_counts, B, capacity, D, d_dst, d_total,
+                       d_meta_src, meta_dst, n_meta);
     vx_prof_end(VX_PROF_PACK, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }

@@ -27,8 +27,13 @@ class DETRPostProcess(nn.Module):
         return ops.pack_rows(rows, meta[B:2 * B]), meta
 
     def forward_async(self, inputs: torch.Tensor, score_threshold, **kwargs) -> PendingDetections:
-        return PendingDetections(*self.forward_device(inputs, score_threshold))
+        if inputs.ndim != 3:
+            raise RuntimeError("DETR postprocess input must have dimension of 3 "
+                               "(num_batch, num_queries, (num_classes + 1) + 4)")
+        rows, meta = ops.detr_decode(inputs, _f(score_threshold))
+        B = inputs.size(0)
+        return PendingDetections.packing(rows, meta[B:2 * B], meta)
 
     @torch.no_grad()
     def forward(self, inputs: torch.Tensor, score_threshold: torch.Tensor, **kwargs) -> torch.Tensor:
-        return finish_results(*self.forward_device(inputs, score_threshold))
+        return self.forward_async(inputs, score_threshold).result()

@@ -234,12 +234,21 @@ def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_
     return batched_nms(c.boxes, c.scores, c.cls, c.det, c.counts, iou_threshold, n_classes, top_k, meta=c.meta)
 
 
-def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor) -> torch.Tensor:
-    """f32[B,cap,D] + i32[B] -> f32[B*cap, D] with the kept rows of all images back to back."""
+def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor, meta: Optional[torch.Tensor] = None,
+              host_meta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32[B,cap,D] + i32[B] -> f32[B*cap, D] with the kept rows of all images back to back.  With `meta`
+    (device i32[n]) and `host_meta` (pinned host i32[n]) the kernel also mirrors the meta words into the pinned
+    buffer, so the caller only waits for an event instead of issuing a D2H copy."""
     B, cap, D = out_det.shape
     packed = torch.empty((B * cap, D), dtype=torch.float32, device=out_det.device)
+    src = dst = None
+    n = 0
+    if host_meta is not None:
+        assert meta is not None and host_meta.is_pinned() and host_meta.dtype == torch.int32 == meta.dtype
+        assert host_meta.numel() == meta.numel() and meta.is_contiguous()
+        src, dst, n = meta.data_ptr(), host_meta.data_ptr(), meta.numel()
     rc = L.lib().vx_pack_rows(out_det.data_ptr(), keep_counts.data_ptr(), B, cap, D, packed.data_ptr(), None,
-                              L.stream_ptr(out_det.device))
+                              src, dst, n, L.stream_ptr(out_det.device))
     L.check(rc, "vx_pack_rows")
     return packed
 

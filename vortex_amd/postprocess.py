@@ -180,13 +180,12 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         """Enqueue the whole post-process plus the D2H copy of the counts and return at once; the
         caller overlaps the next batch's launches with this one's GPU work and calls .result() later
         (serving loops).  forward() == forward_async().result()."""
-        packed, meta = self.forward_device(input, score_threshold, iou_threshold)
-        return PendingDetections(packed, meta)
+        out_det, keep_counts, meta = self.forward_unpacked(input, score_threshold, iou_threshold)
+        return PendingDetections.packing(out_det, keep_counts, meta)
 
     def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
-            out_det, meta = self.forward_device(input, score_threshold, iou_threshold)
-            return finish_results(out_det, meta)
+            return self.forward_async(input, score_threshold, iou_threshold).result()
         n_batch = input.size(0)
         results = []
         for i in range(n_batch):
@@ -211,12 +210,21 @@ class PendingDetections:
     """Result of forward_async: the counts travel to pinned host memory on the launch stream, an
     event marks their arrival; result() waits for that event only (not for later launches)."""
 
-    def __init__(self, packed: torch.Tensor, meta: torch.Tensor):
+    def __init__(self, packed: torch.Tensor, meta: torch.Tensor, host: Optional[torch.Tensor] = None):
         self.packed = packed
-        self._host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
-        self._host.copy_(meta, non_blocking=True)
+        if host is None:
+            host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
+            host.copy_(meta, non_blocking=True)
+        self._host = host
         self._event = torch.cuda.Event()
         self._event.record(torch.cuda.current_stream(meta.device))
+
+    @classmethod
+    def packing(cls, out_det: torch.Tensor, keep_counts: torch.Tensor, meta: torch.Tensor) -> "PendingDetections":
+        """Pack the kept rows and let the pack kernel itself mirror the counts into pinned host memory
+        (vx_pack_rows meta_dst): no D2H memcpy sits between this batch's kernels and the next one's."""
+        host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
+        return cls(ops.pack_rows(out_det, keep_counts, meta, host), meta, host)
 
     def result(self) -> Tuple[torch.Tensor, ...]:
         self._event.synchronize()
@@ -260,8 +268,7 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
         return int(input[0].size(1)) // 3 - 5
 
     def forward(self, input: Sequence[torch.Tensor], score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
-        out_det, meta = self.forward_device(input, score_threshold, iou_threshold)
-        return finish_results(out_det, meta)
+        return self.forward_async(input, score_threshold, iou_threshold).result()
 
 
 class NoOpPostProcess(nn.Module):
