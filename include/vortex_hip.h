@@ -35,7 +35,9 @@ extern "C" {
 
 /* bits of the device status word (int32, caller zeroes it, kernels OR into it) */
 #define VX_STATUS_NAN         1     /* predictions contain NaN: postprocess/yolov3.py:35-36 -> ValueError */
-#define VX_STATUS_BAD_CLASS   2     /* class index outside [0, VX_MAX_CLASSES)           */
+#define VX_STATUS_BAD_CLASS   2     /* class index outside [0, VX_MAX_CLASSES) (or != 0 when n_classes == 1) */
+#define VX_STATUS_RANGE       4     /* NMS: |box coordinate| >= 1024 with more than one class: the per-class
+                                       sweep would differ from the reference's shifted single pass -> refused */
 
 #define VX_MAX_CLASSES        4096  /* sort key holds the class in 12 bits               */
 #define VX_MAX_CANDIDATES     1048575 /* per image; sort key holds the index in 20 bits  */
@@ -151,7 +153,8 @@ int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
  * out_capacity >= min(capacity, top_k>0 ? top_k : capacity).
  * Limits: capacity <= VX_MAX_CANDIDATES, 0 <= cls < VX_MAX_CLASSES (else VX_STATUS_BAD_CLASS),
  * |coordinate| < 1024 so that classes cannot overlap after the offset (always true for
- * normalised boxes), iou_threshold >= 0. */
+ * normalised boxes; checked on the device -> VX_STATUS_RANGE), iou_threshold >= 0.
+ * n_classes == 1 declares class-agnostic NMS (every cls must be 0): no shift, any coordinate range. */
 size_t vx_batched_nms_workspace_bytes(int B, int capacity);
 int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
                    const float *d_det, const int32_t *d_counts,

@@ -228,6 +228,22 @@ def test_batched_nms_iou_exactly_at_threshold(base):
         same(V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), thr_t), ref)
 
 
+def test_nms_coordinate_range_guard():
+    """Per-class sweeps equal the reference's shifted single pass only while |coordinate| < 1024: pixel-unit
+    boxes with several classes are refused loudly; class-agnostic NMS (no shift) takes any range."""
+    boxes, scores, cls = O.synth_stress_boxes(3000, 5, 17)
+    px = (boxes * 1500.0).contiguous()
+    with pytest.raises(V._lib.VortexHipError):
+        V.batched_nms(px.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([0.5]))          # single-launch path
+    big, bs, bc = O.synth_stress_boxes(20000, 5, 18)
+    with pytest.raises(V._lib.VortexHipError):
+        V.batched_nms((big * 1500.0).to(DEV), bs.to(DEV), bc.to(DEV), torch.tensor([0.5]))  # multi-kernel path
+    same(V.postprocess.nms(px.to(DEV), scores.to(DEV), torch.tensor([0.5])), O.nms(px, scores, 0.5))
+    inside = (boxes * 800.0).contiguous()                                                    # |x| <= 920: accepted
+    same(V.batched_nms(inside.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([0.5])),
+         O.batched_nms(inside, scores, cls, torch.tensor([0.5])))
+
+
 def test_nms_class_agnostic_module():
     boxes, scores, _ = O.synth_stress_boxes(1500, 1, 9)
     det = torch.randn(1, 1500, 6)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvortex_hip.so")
 VX_OK = 0
 VX_STATUS_NAN = 1
 VX_STATUS_BAD_CLASS = 2
+VX_STATUS_RANGE = 4
 VX_MAX_CLASSES = 4096
 VX_MAX_CANDIDATES = 1048575
 VX_RESIZE_STRETCH = 0

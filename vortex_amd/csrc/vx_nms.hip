@@ -30,6 +30,13 @@ struct vx_nms_params {
     float thr;
 };
 
+// Class segmentation == the reference's single pass over offset boxes only while boxes of different classes
+// cannot meet after the 2049*cls shift: guaranteed for |coordinate| < 1024 (normalised boxes).  Outside that
+// range the call is refused (VX_STATUS_RANGE) unless the caller declared a single class (no shift at all).
+__device__ __forceinline__ bool vx_box_in_range(const vx_f4 &b) {
+    return !(fabsf(b.x) >= 1024.0f || fabsf(b.y) >= 1024.0f || fabsf(b.z) >= 1024.0f || fabsf(b.w) >= 1024.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restrict__ scores,
                                                            const long long *__restrict__ cls,
@@ -43,6 +50,7 @@ __global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restri
     if (k < n) {
         long long c = cls[(long long)b * p.cap + k];
         if (c < 0 || c >= VX_MAX_CLASSES) { atomicOr(status, VX_STATUS_BAD_CLASS); c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
+        if (p.n_classes == 1 && c != 0) { atomicOr(status, VX_STATUS_BAD_CLASS); c = 0; }
         keys1[(long long)b * p.npad_cap + k] = vx_key1((int)c, scores[(long long)b * p.cap + k], k);
     }
 }
@@ -61,6 +69,7 @@ struct vx_sort_params {
 struct vx_epi_params {
     // epilogue 1
     const float *boxes; vx_f4 *sbox; float *sarea; int cap;
+    int *status; int guard;       // guard != 0: flag |coordinate| >= 1024 (see vx_box_in_range)
     // epilogue 2
     const float *det; long long *keep_idx; float *out_det; int *keep_counts; int D, top_k, out_cap;
 };
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
                 int idx = vx_key1_idx(key);
                 float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
                 vx_f4 bx = *reinterpret_cast<const vx_f4 *>(ep.boxes + ((long long)b * ep.cap + idx) * 4);
+                if (ep.guard && !vx_box_in_range(bx)) atomicOr(ep.status, VX_STATUS_RANGE);
                 bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
                 long long o = (long long)b * sp.stride + gi;
                 ep.sbox[o] = bx;
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         if (i < n) {
             long long c = a.cls[ib + i];
             if (c < 0 || c >= VX_MAX_CLASSES) { bad = true; c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
+            if (p.n_classes == 1 && c != 0) { bad = true; c = 0; }
             key = vx_key1((int)c, a.scores[ib + i], i);
         }
         sk[i] = key;
@@ -617,14 +628,17 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
     vx_f4 *sb = a.sbox + ob;
     float *sa = a.sarea + ob;
+    bool oob = false;
     for (int i = threadIdx.x; i < n; i += nt) {
         u64 key = sk[i];
         float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
         vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
+        oob |= !vx_box_in_range(bx);
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         sb[i] = bx;
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
     }
+    if (p.n_classes != 1 && __ballot(oob) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_RANGE);
     __syncthreads();
     VX_STAMP(3);
     u64 *k2 = a.keys2 + ob;
@@ -815,6 +829,7 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     vx_prof_end(VX_PROF_NMS_KEYS, st);
     vx_epi_params ep = {};
     ep.boxes = d_boxes; ep.sbox = w.sbox; ep.sarea = w.sarea; ep.cap = capacity;
+    ep.status = d_status; ep.guard = n_classes != 1;
     ep.det = d_det; ep.keep_idx = (long long *)d_keep_idx; ep.out_det = d_out_det; ep.keep_counts = d_keep_counts;
     ep.D = D; ep.top_k = top_k; ep.out_cap = out_capacity;
     vx_prof_begin(VX_PROF_SORT1, st);

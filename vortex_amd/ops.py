@@ -274,3 +274,7 @@ def raise_on_status(status: int):
         raise ValueError("your predictions have nan! please check")
     if status & L.VX_STATUS_BAD_CLASS:
         raise L.VortexHipError("class index outside [0, %d): not supported by libvortex_hip" % L.VX_MAX_CLASSES)
+    if status & L.VX_STATUS_RANGE:
+        raise L.VortexHipError("class-aware NMS needs box coordinates inside (-1024, 1024) (normalised boxes): beyond "
+                               "that the reference's 2049*class shift lets classes overlap, which the per-class "
+                               "sweep of libvortex_hip does not reproduce")

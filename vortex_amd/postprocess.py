@@ -77,7 +77,7 @@ def _check_ranks(class_indexes, scores, bboxes, detections):
         raise RuntimeError("current version only support single batch")
 
 
-def _nms_single(boxes, scores, idxs, det, iou_threshold, top_k=None):
+def _nms_single(boxes, scores, idxs, det, iou_threshold, top_k=None, n_classes=0):
     """One image through vx_batched_nms; returns (keep i64[K'], gathered det f32[1,K',D] or None)."""
     K = int(boxes.shape[0])
     if boxes.numel() == 0:
@@ -86,7 +86,7 @@ def _nms_single(boxes, scores, idxs, det, iou_threshold, top_k=None):
         det = boxes.new_zeros((K, 1))
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.reshape(1, K, 4).float(), scores.reshape(1, K).float(), idxs.reshape(1, K).to(torch.int64),
-        det.reshape(1, K, -1).float(), None, _f(iou_threshold), 0, top_k)
+        det.reshape(1, K, -1).float(), None, _f(iou_threshold), n_classes, top_k)
     meta = torch.cat((keep_counts, status)).cpu()
     ops.raise_on_status(int(meta[1]))
     n = int(meta[0])
@@ -102,7 +102,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 def nms(boxes, scores, iou_threshold):
     """Class-agnostic greedy NMS (what the reference gets from torchvision.ops.nms)."""
     idxs = torch.zeros(scores.shape, dtype=torch.int64, device=scores.device)
-    return _nms_single(boxes, scores, idxs, None, iou_threshold)[0]
+    return _nms_single(boxes, scores, idxs, None, iou_threshold, n_classes=1)[0]    # one class: any coordinate range
 
 
 class NMS(nn.Module):
@@ -114,7 +114,7 @@ class NMS(nn.Module):
         if bboxes.numel() == 0:
             return detections[:, :0]
         idxs = torch.zeros(scores.shape, dtype=torch.int64, device=scores.device)
-        return _nms_single(bboxes, scores, idxs, detections[0], iou_threshold)[1]
+        return _nms_single(bboxes, scores, idxs, detections[0], iou_threshold, n_classes=1)[1]
 
 
 class BatchedNMS(nn.Module):
