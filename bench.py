@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the detection lists every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra pass that times the opt-in variants")
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight: 1 = synchronous API call per step (forward()), 2 = forward_async(): "
                          "the launches of step i+1 are enqueued before the results of step i are collected")
@@ -238,7 +239,7 @@ def main():
     # Opt-in decode variant, reported beside the contract line (never as `value`): same detections, but the NaN
     # check of the reference is restricted to objectness + surviving rows, so most of the head bytes are not read.
     variants = {}
-    if world == 1 and not (args.unfused or args.allgather or args.threshold_first):
+    if world == 1 and not (args.unfused or args.allgather or args.threshold_first or args.no_variants):
         post_full = post
         post = V.YoloV3FusedPostProcess(img_size=S, nan_check="survivors")
         run_steps(3)
