@@ -134,7 +134,6 @@ struct vx_rows_params {
     int B, R, C, NP, tiles_per_img;
     float img_size, thr;
     int use_thr;
-    int sparse_max;     // threshold-first: tiles with more survivors than this are streamed
 };
 
 __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__restrict__ pred,
@@ -245,14 +244,23 @@ __device__ __forceinline__ int vx_fused_tile_row0(const vx_fused_params &p, int 
 template <int V>
 struct vx_cells { float v[V]; };
 
+// 16-B load that only needs dword alignment (gfx950 global loads allow it): planes of G*G floats start at any
+// multiple of 4 bytes.  nv < 4: the lane owns the last 1..3 cells of a plane -> scalar loads, never past it.
+typedef float vx_v4u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int V, bool NT>
-__device__ __forceinline__ vx_cells<V> vx_load_cells(const float *p) {
+__device__ __forceinline__ vx_cells<V> vx_load_cells(const float *p, int nv = V) {
     vx_cells<V> c;
     if constexpr (V == 4) {
-        vx_v4 q;
-        if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(p));
-        else q = *reinterpret_cast<const vx_v4 *>(p);
-        c.v[0] = q.x; c.v[1] = q.y; c.v[2] = q.z; c.v[3] = q.w;
+        if (nv == 4) {
+            vx_v4u q;
+            if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const vx_v4u *>(p));
+            else q = *reinterpret_cast<const vx_v4u *>(p);
+            c.v[0] = q.x; c.v[1] = q.y; c.v[2] = q.z; c.v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c.v[j] = j < nv ? p[j] : 0.f;
+        }
     } else {
         if constexpr (NT) c.v[0] = __builtin_nontemporal_load(p);
         else c.v[0] = *p;
@@ -261,13 +269,15 @@ __device__ __forceinline__ vx_cells<V> vx_load_cells(const float *p) {
 }
 
 // VX_FUSED_UN: channel planes per register batch (UN x 1 KiB per wave in flight per batch)
-template <int V, int VX_FUSED_UN, bool NT>
+template <int V, int VX_FUSED_UN, bool NT, bool PARTIAL = false>
 __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx_scale_desc &s, int b, int a,
                                               int cell0, int row0, int tile, vx_rec *stage, int *tile_counts,
                                               int *status) {
     const int lane = vx_lane();
     const int c0 = cell0 + lane * V;                 // first cell of this lane
-    const bool live = c0 < s.cells;                  // cells % V == 0 -> all V cells live or none
+    const int nv = min(max(s.cells - c0, 0), V);     // valid cells of this lane (the last lane of a plane may own < V)
+    const bool live = nv > 0;
+    const int nvl = PARTIAL ? nv : V;                // !PARTIAL: every live lane owns V cells -> branch-free vector loads
     const long long cells = s.cells;
     const float *plane = s.ptr + ((long long)(b * 3 + a) * p.NP) * cells + c0;
     float best[V];
@@ -288,13 +298,13 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
         vx_cells<V> A[VX_FUSED_UN], Bt[VX_FUSED_UN];
 #pragma unroll
         for (int u = 0; u < VX_FUSED_UN; ++u)
-            if (u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)u * cells);
+            if (u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)u * cells, nvl);
 #pragma unroll
-        for (int ch = 0; ch < 5; ++ch) tb[ch] = vx_load_cells<V, NT>(plane + (long long)ch * cells);
+        for (int ch = 0; ch < 5; ++ch) tb[ch] = vx_load_cells<V, NT>(plane + (long long)ch * cells, nvl);
         for (int k0 = 0; k0 < C; k0 += 2 * VX_FUSED_UN) {
 #pragma unroll
             for (int u = 0; u < VX_FUSED_UN; ++u)
-                if (k0 + VX_FUSED_UN + u < C) Bt[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + VX_FUSED_UN + u) * cells);
+                if (k0 + VX_FUSED_UN + u < C) Bt[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + VX_FUSED_UN + u) * cells, nvl);
 #pragma unroll
             for (int u = 0; u < VX_FUSED_UN; ++u) {
                 const int k = k0 + u;
@@ -310,7 +320,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
             }
 #pragma unroll
             for (int u = 0; u < VX_FUSED_UN; ++u)
-                if (k0 + 2 * VX_FUSED_UN + u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + 2 * VX_FUSED_UN + u) * cells);
+                if (k0 + 2 * VX_FUSED_UN + u < C) A[u] = vx_load_cells<V, NT>(cp + (long long)(k0 + 2 * VX_FUSED_UN + u) * cells, nvl);
 #pragma unroll
             for (int u = 0; u < VX_FUSED_UN; ++u) {
                 const int k = k0 + VX_FUSED_UN + u;
@@ -338,7 +348,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         obj[j] = live ? vx_sigmoid(tb[4].v[j]) : 0.f;
-        pass[j] = live && (p.use_thr ? (obj[j] > p.thr) : true);
+        pass[j] = j < nv && (p.use_thr ? (obj[j] > p.thr) : true);
         m[j] = __ballot(pass[j]);
         below += vx_mbcnt(m[j]);
         total += __popcll(m[j]);
@@ -373,13 +383,14 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
                                                      int *status) {
     const int lane = vx_lane();
     const int c0 = cell0 + lane * V;
-    const bool live = c0 < s.cells;
+    const int nv = min(max(s.cells - c0, 0), V);
+    const bool live = nv > 0;
     const long long cells = s.cells;
     const float *base = s.ptr + ((long long)(b * 3 + a) * p.NP) * cells;      // channel 0, cell 0 of this plane set
     vx_cells<V> to;
 #pragma unroll
     for (int j = 0; j < V; ++j) to.v[j] = 0.f;
-    if (live) to = vx_load_cells<V, false>(base + 4 * cells + c0);
+    if (live) to = vx_load_cells<V, false>(base + 4 * cells + c0, nv);
     bool nan = false;
     float obj[V];
     bool pass[V];
@@ -389,7 +400,7 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
     for (int j = 0; j < V; ++j) {
         nan |= (to.v[j] != to.v[j]);
         obj[j] = live ? vx_sigmoid(to.v[j]) : 0.f;
-        pass[j] = live && (obj[j] > p.thr);
+        pass[j] = j < nv && (obj[j] > p.thr);
         m[j] = __ballot(pass[j]);
         below += vx_mbcnt(m[j]);
         total += __popcll(m[j]);
@@ -455,8 +466,9 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec
                   : vx_fused_tile_sparse<1>(p, s, b, a, cell0, row0, t, stage, tile_counts, status))
             return;
     }
-    if (s.vec) vx_fused_tile<4, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
-    else vx_fused_tile<1, UN, NT>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
+    const bool partial = (s.cells & 3) != 0 && cell0 + s.tile_cells >= s.cells;   // wave-uniform: last tile of an odd plane
+    if (partial) vx_fused_tile<4, UN, NT, true>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
+    else vx_fused_tile<4, UN, NT, false>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -606,7 +618,7 @@ static int vx_fused_setup(vx_fused_params &p, const float *h0, const float *h1, 
         s.G = S / div[i];
         if (s.G <= 0) return VX_ERR_INVALID_ARG;
         s.cells = s.G * s.G;
-        s.vec = (s.cells % 4 == 0) && (((uintptr_t)ptrs[i] & 15) == 0);
+        s.vec = 1;      // 16-B loads need dword alignment only (vx_v4u); a plane's last lane may own < 4 cells
         s.tile_cells = s.vec ? 256 : 64;
         s.tiles_per_plane = (s.cells + s.tile_cells - 1) / s.tile_cells;
         s.tile_base = tile_base;
@@ -683,7 +695,10 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_FUSED, st);
     // <2, true>: 2 channel planes per register batch in ping-pong (7 waves/SIMD), non-temporal loads.
-    // A/B on MI355X, B=256 (tools/ab_fused.py): UN 8/4/3/2/1 with nt = 5.0/5.9/5.9/6.19/5.96 TB/s, UN 4/2 plain = 5.5/5.67.
+    // A/B on MI355X, B=256 (tools/ab_fused.py): UN 8/4/3/2/1 with nt = 5.0/5.9/5.9/6.19/5.96 TB/s, UN 4/2 plain = 5.5/5.67;
+    // one batch of 4/5/8/10/16/20 planes without ping-pong = 5.88/5.98/5.97/6.02/6.10/5.70.  Ceilings measured on the
+    // same box (tools/micro/read_bw.hip): linear 16-B nt read 7.1 TB/s, this kernel's plane-strided address pattern
+    // without arithmetic 6.5 (2 planes in flight) .. 6.9 (12), linear read + sigmoid/max arithmetic 6.8.
     if (sparse)
         hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
