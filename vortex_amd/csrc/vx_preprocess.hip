@@ -82,6 +82,46 @@ __global__ __launch_bounds__(256) void vx_k_normalize_vec(const uint8_t *__restr
     }
 }
 
+// Same work with blockIdx.y = image: no 64-bit division per group, 32-bit indexing inside an image.
+template <int UNR>
+__global__ __launch_bounds__(256) void vx_k_normalize_img(const uint8_t *__restrict__ src, float *__restrict__ dst,
+                                                          int quads_per_img, vx_norm_params p) {
+    __shared__ float lut[768];
+    vx_build_lut(lut, p);
+    const float *l0 = lut, *l1 = lut + 256, *l2 = lut + 512;
+    const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;
+    const long long HW = (long long)quads_per_img * 4;
+    const uint8_t *simg = src + (long long)blockIdx.y * HW * 3;
+    float *dimg = dst + (long long)blockIdx.y * HW * 3;
+    const int stride = gridDim.x * 256;
+    for (int q0 = blockIdx.x * 256 + threadIdx.x; q0 < quads_per_img; q0 += stride * UNR) {
+        vx_u3v w[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int q = q0 + u * stride;
+            if (q < quads_per_img) w[u] = *reinterpret_cast<const vx_u3v *>(simg + (long long)q * 12);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int q = q0 + u * stride;
+            if (q < quads_per_img) {
+                unsigned char px[12];
+                *reinterpret_cast<unsigned *>(px + 0) = w[u].x;
+                *reinterpret_cast<unsigned *>(px + 4) = w[u].y;
+                *reinterpret_cast<unsigned *>(px + 8) = w[u].z;
+                vx_v4 o0, o1, o2;
+                o0.x = l0[px[0 + s0]]; o0.y = l0[px[3 + s0]]; o0.z = l0[px[6 + s0]]; o0.w = l0[px[9 + s0]];
+                o1.x = l1[px[1]];      o1.y = l1[px[4]];      o1.z = l1[px[7]];      o1.w = l1[px[10]];
+                o2.x = l2[px[0 + s2]]; o2.y = l2[px[3 + s2]]; o2.z = l2[px[6 + s2]]; o2.w = l2[px[9 + s2]];
+                float *d = dimg + (long long)q * 4;
+                __builtin_nontemporal_store(o0, reinterpret_cast<vx_v4 *>(d));
+                __builtin_nontemporal_store(o1, reinterpret_cast<vx_v4 *>(d + HW));
+                __builtin_nontemporal_store(o2, reinterpret_cast<vx_v4 *>(d + 2 * HW));
+            }
+        }
+    }
+}
+
 // Scalar fallback (HW % 4 != 0 or misaligned pointers): one thread = one pixel.
 __global__ __launch_bounds__(256) void vx_k_normalize_scalar(const uint8_t *__restrict__ src,
                                                              float *__restrict__ dst,
@@ -153,16 +193,13 @@ __device__ __forceinline__ void vx_resize_pixel(const uint8_t *__restrict__ src,
 // resize only: u8 HWC -> u8 HWC (BaseRuntime.resize_batch, basic_runtime.py:75-90)
 __global__ __launch_bounds__(256) void vx_k_resize_u8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                       int B, vx_resize_params r) {
-    const long long HWd = (long long)r.Hd * r.Wd;
-    const long long total = HWd * B;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        int b = (int)(i / HWd);
-        int pp = (int)(i - (long long)b * HWd);
+    const int HWd = r.Hd * r.Wd;                     // blockIdx.y = image: 32-bit index math inside an image
+    const int b = blockIdx.y;
+    for (int pp = blockIdx.x * 256 + threadIdx.x; pp < HWd; pp += gridDim.x * 256) {
         int y = pp / r.Wd, x = pp - y * r.Wd;
         int v0, v1, v2;
         vx_resize_pixel(src, r, b, y, x, v0, v1, v2);
-        uint8_t *d = dst + i * 3;
+        uint8_t *d = dst + ((long long)b * HWd + pp) * 3;
         d[0] = (uint8_t)v0; d[1] = (uint8_t)v1; d[2] = (uint8_t)v2;
     }
 }
@@ -174,11 +211,8 @@ __global__ __launch_bounds__(256) void vx_k_resize_normalize(const uint8_t *__re
     vx_build_lut(lut, p);
     const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;
     const long long HWd = (long long)r.Hd * r.Wd;
-    const long long total = HWd * B;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        int b = (int)(i / HWd);
-        int pp = (int)(i - (long long)b * HWd);
+    const int b = blockIdx.y;
+    for (int pp = blockIdx.x * 256 + threadIdx.x; pp < (int)HWd; pp += gridDim.x * 256) {
         int y = pp / r.Wd, x = pp - y * r.Wd;
         int v0, v1, v2;
         vx_resize_pixel(src, r, b, y, x, v0, v1, v2);
@@ -219,9 +253,9 @@ extern "C" int vx_resize_u8hwc(const uint8_t *d_src, uint8_t *d_dst, int B, int 
     if (pad_value < 0 || pad_value > 255) return VX_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
-    long long total = (long long)Hd * Wd * B;
+    if ((long long)Hd * Wd >= (1LL << 30) || B > 65535) return VX_ERR_UNSUPPORTED;
     vx_prof_begin(VX_PROF_PREPROCESS, st);
-    hipLaunchKernelGGL(vx_k_resize_u8, dim3(vx_grid_for(total, 256, 256 * 8)), dim3(256), 0, st, d_src, d_dst, B, r);
+    hipLaunchKernelGGL(vx_k_resize_u8, dim3(vx_grid_for((long long)Hd * Wd, 1024, 4096), B), dim3(256), 0, st, d_src, d_dst, B, r);
     vx_prof_end(VX_PROF_PREPROCESS, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
@@ -245,9 +279,16 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
         long long HW = (long long)Hs * Ws;
         bool vec = (HW % 4 == 0) && (((uintptr_t)d_src & 3) == 0) && (((uintptr_t)d_dst & 15) == 0);
         if (vec) {
-            // A/B on MI355X, B=256 (tools/ab_norm.py): plain loads + 2 groups in flight + non-temporal stores
+            // flat-index kernel, A/B on MI355X, B=256: plain loads + 2 groups in flight + non-temporal stores
             // = 5.70 TB/s; nt loads 5.45; 1 group 4.85; plain stores 4.9; 3-4 groups or a 4096-block grid: no change.
             long long qpi = HW / 4, total = qpi * B;
+            if (qpi < (1LL << 28) && B <= 65535) {
+                // blockIdx.y = image, 4 groups in flight, 2 trips per thread: no 64-bit division per group.
+                // A/B (tools/ab_norm.py): 6.82 TB/s; 2 groups x 4 trips 6.78, 1 x 8 6.75, 4 x 4 6.69; the flat-index
+                // kernel below (one 64-bit division per group) 5.72.
+                int gx = (int)((qpi + 2047) / 2048);
+                hipLaunchKernelGGL((vx_k_normalize_img<4>), dim3(gx, B), dim3(256), 0, st, d_src, d_dst, (int)qpi, p);
+            } else
             hipLaunchKernelGGL((vx_k_normalize_vec<false, 2>), dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
                                d_src, d_dst, qpi, total, p);
         } else {
@@ -257,8 +298,8 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
         }
     } else {
         vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
-        long long total = (long long)Hd * Wd * B;
-        hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for(total, 256, max_blocks)), dim3(256), 0, st,
+        if ((long long)Hd * Wd >= (1LL << 30) || B > 65535) { vx_prof_end(VX_PROF_PREPROCESS, st); return VX_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for((long long)Hd * Wd, 1024, 4096), B), dim3(256), 0, st,
                            d_src, d_dst, B, r, p);
     }
     vx_prof_end(VX_PROF_PREPROCESS, st);
