@@ -453,11 +453,11 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
 template <int UN, bool NT, bool SPARSE>
 __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
                                                        int *__restrict__ tile_counts, int *__restrict__ status) {
-    long long wtile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    long long total = (long long)p.B * p.tiles_per_img;
-    if (wtile >= total) return;
-    int b = (int)(wtile / p.tiles_per_img);
-    int t = (int)(wtile - (long long)b * p.tiles_per_img);
+    // 32-bit index math (the host refuses B * tiles_per_img >= 2^31): no 64-bit division per wave
+    const unsigned wtile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wtile >= (unsigned)p.B * (unsigned)p.tiles_per_img) return;
+    int b = (int)(wtile / (unsigned)p.tiles_per_img);
+    int t = (int)(wtile - (unsigned)b * (unsigned)p.tiles_per_img);
     int si, a, cell0;
     int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
     const vx_scale_desc &s = p.s[si];                 // wave-uniform
@@ -691,7 +691,7 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     int *tile_counts = (int *)((char *)d_workspace + vx_align256((size_t)B * p.R * sizeof(vx_rec)));
     long long waves = (long long)B * p.tiles_per_img;
     long long nblk = (waves + 3) / 4;
-    if (nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+    if (waves + 4 > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_FUSED, st);
     // <2, true>: 2 channel planes per register batch in ping-pong (7 waves/SIMD), non-temporal loads.
