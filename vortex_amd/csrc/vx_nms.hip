@@ -836,11 +836,13 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     int rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
     vx_prof_end(VX_PROF_SORT1, st);
     if (rc != VX_OK) return rc;
-    // few classes -> few, long segments: 16 waves per segment; many classes -> many segments side by side
-    // (4 waves each).  One class per wave and pass; <= 4096/32 = 128 = VX_SWEEP_MAXBIG classes per workgroup.
-    const int sweep_threads = n_classes <= 8 ? 1024 : 256;
-    int X = n_classes <= 8 ? n_classes : (n_classes + 3) / 4;
-    if (X > 32) X = 32;
+    // One class per wave and pass; <= 4096/256 = 16 <= VX_SWEEP_MAXBIG classes per workgroup.
+    // A/B on MI355X (tools/bench_configs.py), sweep kernel ms for (threads, workgroups per image):
+    //   FPN-SSD 20 classes x ~1500 boxes, b64:   (256,5) 2.43  (256,20) 0.88  (512,20) 0.84  (1024,20) 1.01
+    //   stress 80 classes x 1250 boxes, b32:     (256,20) 2.10 (256,80) 1.20  (512,80) 1.12  (1024,80) 1.51
+    // -> one workgroup per class (8 waves) up to 256 workgroups per image; <= 8 classes: 16 waves per class.
+    const int sweep_threads = n_classes <= 8 ? 1024 : 512;
+    int X = n_classes <= 256 ? n_classes : 256;
     if (X < 1) X = 1;
     vx_prof_begin(VX_PROF_SWEEP, st);
     hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
