@@ -30,15 +30,31 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict
     const int n = nrow * NCOL;
     bool nan = false;
     {
-        // element e = threadIdx.x + 256*k  ->  (row, col) advanced incrementally (no division in the loop)
-        int row = threadIdx.x / NCOL, col = threadIdx.x - row * NCOL;
-        const int drow = 256 / NCOL, dcol = 256 - drow * NCOL;
-        for (int e = threadIdx.x; e < n; e += 256) {
-            float v = g[e];
-            nan |= (v != v);
-            tile[row * NCP + col] = v;
+        // 16-B flat loads of the contiguous tile (dword alignment suffices); float4 f = threadIdx.x + 256*k covers
+        // elements 4f..4f+3 -> (row, col) advanced incrementally, rows padded to the odd stride NCP in LDS
+        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+        const int n4 = n >> 2;
+        int e0 = threadIdx.x * 4;
+        int row = e0 / NCOL, col = e0 - row * NCOL;
+        const int drow = 1024 / NCOL, dcol = 1024 - drow * NCOL;
+        for (int f = threadIdx.x; f < n4; f += 256) {
+            v4u q = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(g + 4 * f));
+            float v[4] = {q.x, q.y, q.z, q.w};
+            int rr = row, cc = col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nan |= (v[j] != v[j]);
+                tile[rr * NCP + cc] = v[j];
+                if (++cc == NCOL) { cc = 0; ++rr; }
+            }
             row += drow; col += dcol;
             if (col >= NCOL) { col -= NCOL; ++row; }
+        }
+        for (int e = n4 * 4 + threadIdx.x; e < n; e += 256) {       // < 4 leftover floats of a partial last tile
+            float v = g[e];
+            nan |= (v != v);
+            int rr = e / NCOL;
+            tile[rr * NCP + (e - rr * NCOL)] = v;
         }
     }
     if (__ballot(nan) != 0 && vx_lane() == 0) atomicOr(status, VX_STATUS_NAN);
@@ -50,15 +66,28 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict
     int ci = 0;
     const float *row = tile + r * NCP;
     if (r < nrow) {
-        const float *lg = row + 4 + 2 * p.L;
+        float *lg = tile + r * NCP + 4 + 2 * p.L;
         float m = lg[0];
         for (int k = 1; k < p.NC; ++k) m = lg[k] > m ? lg[k] : m;
-        float sum = 0.f;
-        for (int k = 0; k < p.NC; ++k) sum = sum + vx_exp(lg[k] - m);
-        conf = -1.f;
+        // one exp per logit: e_k replaces the logit in LDS, sum in class order, (max e, first index) on the way
+        float e0 = vx_exp(lg[0] - m);
+        float sum = 0.f + e0, emax = -1.f;
+        int kmax = 1;
         for (int k = 1; k < p.NC; ++k) {
-            float c = vx_exp(lg[k] - m) / sum;
-            if (c > conf) { conf = c; ci = k - 1; }
+            float e = vx_exp(lg[k] - m);
+            lg[k] = e;
+            sum = sum + e;
+            if (e > emax) { emax = e; kmax = k; }
+        }
+        // max_k fl(e_k/sum) == fl(max_k e_k / sum): a correctly rounded division is monotonic in its numerator
+        conf = emax / sum;
+        ci = kmax - 1;
+        // "first index of the maximum probability": an earlier class whose e is within an ulp or two of emax can
+        // round to the same quotient -- the only case that needs another division
+        const float near = emax * 0.999999f;
+        for (int k = 1; k < kmax; ++k) {
+            float e = lg[k];
+            if (e >= near && e / sum == conf) { ci = k - 1; break; }
         }
         pass = p.use_thr ? (conf > p.thr) : true;
     }
