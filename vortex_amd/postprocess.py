@@ -127,6 +127,13 @@ class BatchedNMS(nn.Module):
         _check_ranks(class_indexes, scores, bboxes, detections)
         if bboxes.numel() == 0:
             return detections[:, :0]
+        if self.nms_fn is not batched_nms:
+            # exporter hook (reference exporter/torchscript.py:38-41 swaps nms_fn before tracing): keep indices
+            # from the replacement op, then the reference's index_select (nms.py:122)
+            keep = self.nms_fn(bboxes, scores, class_indexes, _f(iou_threshold))
+            if self.top_k is not None:
+                keep = keep[:self.top_k]
+            return detections.index_select(1, keep)
         return _nms_single(bboxes, scores, class_indexes, detections[0], iou_threshold, self.top_k)[1]
 
 
