@@ -2,10 +2,11 @@
 """Parity CLI: the repo's counterpart of the reference's export check (scripts/export_check/onnx_check.py:249-314:
 random uint8 input, thresholds 0.0 / 1.0 by default, predictor output of one backend compared with another with
 isclose(rtol 1e-3, atol 1e-6)).  Here the two "backends" are the HIP path (through the C ABI) and the CPU oracle,
-on the same seeded synthetic inputs, and the bars are the repo's own: bit-exact for integer / index work,
+on the same seeded synthetic inputs (test infrastructure: it lives under tests/ because it runs the oracle as the
+checker), and the bars are the repo's own: bit-exact for integer / index work,
 1e-5 relative for the sigmoid/exp/softmax stages.  One line per check, exit code 1 on any failure.
 
-    python tools/parity_check.py [--score-threshold 0.0 --iou-threshold 1.0] [--batch 4] [--seed 0]"""
+    python tests/parity_cli.py [--score-threshold 0.0 --iou-threshold 1.0] [--batch 4] [--seed 0]"""
 import argparse
 import os
 import sys

@@ -13,7 +13,6 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 import vortex_amd as V  # noqa: E402
 from vortex_amd import _lib as L, ops  # noqa: E402
-from oracle import vortex_oracle as O  # noqa: E402  (synthetic-input generators only)
 
 dev = torch.device("cuda:0")
 
@@ -37,9 +36,25 @@ def run(name, fn, images, steps=20, warmup=3, extra=None):
     print(json.dumps(d), flush=True)
 
 
+def make_priors(img_size=640):
+    """6 normalised (cx,cy,w,h) priors per cell on strides 8/16/32: P = 50400 at 640 (timing input only)."""
+    out = []
+    for s in (8, 16, 32):
+        g = img_size // s
+        ys, xs = torch.meshgrid(torch.arange(g).float(), torch.arange(g).float(), indexing="ij")
+        cx, cy = ((xs + 0.5) * s / img_size).reshape(-1, 1), ((ys + 0.5) * s / img_size).reshape(-1, 1)
+        per = []
+        for k in range(2):
+            base = s * 4 * (2 ** (k / 2)) / img_size
+            for ar in (1, 2, 3):
+                per.append(torch.cat((cx, cy, torch.full_like(cx, base * ar ** 0.5), torch.full_like(cx, base / ar ** 0.5)), 1))
+        out.append(torch.stack(per, 1).reshape(-1, 4))
+    return torch.cat(out, 0).float().contiguous()
+
+
 def prior_cfg(name, B, Lm, NL, sthr):
     P = 50400
-    priors = O.make_priors(640).to(dev)
+    priors = make_priors(640).to(dev)
     g = torch.Generator(device=dev).manual_seed(5)
     x = torch.randn(B, P, 4 + 2 * Lm + NL, generator=g, device=dev)
     x[..., 4 + 2 * Lm + 1:] = x[..., 4 + 2 * Lm + 1:] * 2 - 3
