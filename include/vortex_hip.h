@@ -211,6 +211,10 @@ int vx_profile_select(unsigned slot_mask);
 int vx_profile_disable(void);
 int vx_profile_slots(void);
 int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, float *min_ms, float *max_ms);
+/* Diagnostics of the single-launch NMS kernel: while profiling is enabled, workgroup b writes 8 shader-clock
+ * stamps (keys, sort, gather, wave sweeps, block sweeps, second sort, output) as u64[B][8] at this byte offset of
+ * the workspace handed to vx_batched_nms (0 if the arguments are out of range). */
+size_t vx_batched_nms_stamps_offset(int B, int capacity);
 
 #ifdef __cplusplus
 }

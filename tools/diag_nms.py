@@ -16,13 +16,12 @@ B = 256
 img, heads = bench.synth_on_device(B, dev, 1234)
 c = ops.yolo_fused_decode(heads, 416, thr)
 lib = L.lib()
-lib.vx_batched_nms_stamps_offset.restype = ctypes.c_size_t
-lib.vx_batched_nms_stamps_offset.argtypes = [ctypes.c_int, ctypes.c_int]
 K = c.R
 nb = lib.vx_batched_nms_workspace_bytes(B, K)
 ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 keep_idx = torch.empty((B, K), dtype=torch.int64, device=dev)
 out_det = torch.empty((B, K, 6), device=dev)
+L.profile_enable(64)                                  # the kernel writes its phase clocks only while profiling
 for it in range(3):
     rc = lib.vx_batched_nms(c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(), c.det.data_ptr(),
                             c.counts.data_ptr(), B, K, 6, 80, 0.2, 0, keep_idx.data_ptr(), out_det.data_ptr(),

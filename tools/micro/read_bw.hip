@@ -54,7 +54,29 @@ __global__ __launch_bounds__(256) void k_read_planes(const float *__restrict__ p
     long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (long long)sets * tiles) return;
     int set = (int)(w / tiles), t = (int)(w % tiles);
-    const float *q = p + ((long long)set * NP) * cells + (long long)t * 256 + (threadIdx.x & 63) * 4;
+    const int c0 = t * 256 + (threadIdx.x & 63) * 4;
+    if (c0 + 4 > cells) return;
+    const float *q = p + ((long long)set * NP) * cells + c0;
+    float acc = 0.f;
+    for (int ch = 0; ch + UN <= NP; ch += UN) {
+        v4 r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const v4 *a = reinterpret_cast<const v4 *>(q + (long long)(ch + u) * cells);
+            r[u] = NT ? __builtin_nontemporal_load(a) : *a;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc += r[u].x + r[u].y + r[u].z + r[u].w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+// one workgroup per plane set: its waves walk the NP contiguous planes together (a linear stream per workgroup)
+template <int UN, bool NT>
+__global__ void k_read_setwg(const float *__restrict__ p, int NP, long long cells, float *out) {
+    const int f = threadIdx.x;                       // float4 index inside a plane
+    if (f * 4 + 4 > cells) return;
+    const float *q = p + ((long long)blockIdx.x * NP) * cells + f * 4;
     float acc = 0.f;
     for (int ch = 0; ch + UN <= NP; ch += UN) {
         v4 r[UN];
@@ -70,9 +92,27 @@ __global__ __launch_bounds__(256) void k_read_planes(const float *__restrict__ p
 }
 
 template <int UN, bool NT>
-static void run_planes(const float *d, float *out, const char *name) {
-    const int sets = 768, tiles = 11, NP = 84;     // G=52 geometry (cells padded to 11*256), NP % UN == 0
-    const long long cells = 2816;
+static void run_setwg(const float *d, float *out, const char *name, int sets, long long cells) {
+    const int NP = 84;
+    int threads = (int)((cells / 4 + 63) / 64) * 64;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_read_setwg<UN, NT>), dim3(sets), dim3(threads), 0, 0, d, NP, cells, out);
+    hipEventRecord(e0);
+    const int it = 20;
+    for (int w = 0; w < it; ++w) hipLaunchKernelGGL((k_read_setwg<UN, NT>), dim3(sets), dim3(threads), 0, 0, d, NP, cells, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    ms /= it;
+    double bytes = (double)sets * NP * cells * 4;
+    printf("%-18s set-per-WG (%d thr) sets %d cells %lld: %.4f ms  %.0f GB/s\n", name, threads, sets, cells, ms, bytes / ms / 1e6);
+}
+
+template <int UN, bool NT>
+static void run_planes(const float *d, float *out, const char *name, int sets = 768, long long cells = 2816) {
+    const int NP = 84;                              // NP % UN == 0
+    const int tiles = (int)((cells + 255) / 256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int blocks = (sets * tiles + 3) / 4;
@@ -85,7 +125,7 @@ static void run_planes(const float *d, float *out, const char *name) {
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     ms /= it;
     double bytes = (double)sets * NP * cells * 4;
-    printf("%-18s planes pattern: %.4f ms  %.0f GB/s\n", name, ms, bytes / ms / 1e6);
+    printf("%-18s planes pattern sets %d cells %lld: %.4f ms  %.0f GB/s\n", name, sets, cells, ms, bytes / ms / 1e6);
 }
 
 template <int UN, bool NT>
@@ -131,6 +171,18 @@ int main() {
     run_planes<4, true>((const float *)d, out, "UN4 nt");
     run_planes<4, false>((const float *)d, out, "UN4 plain");
     run_planes<12, true>((const float *)d, out, "UN12 nt");
+    run_planes<2, true>((const float *)d, out, "UN2 nt G52", 768, 2704);
+    run_planes<4, true>((const float *)d, out, "UN4 nt G52", 768, 2704);
+    run_planes<2, true>((const float *)d, out, "UN2 nt G26", 3072, 676);
+    run_planes<4, true>((const float *)d, out, "UN4 nt G26", 3072, 676);
+    run_setwg<2, true>((const float *)d, out, "UN2 nt G52", 768, 2704);
+    run_setwg<4, true>((const float *)d, out, "UN4 nt G52", 768, 2704);
+    run_setwg<6, true>((const float *)d, out, "UN6 nt G52", 768, 2704);
+    run_setwg<2, true>((const float *)d, out, "UN2 nt G26", 3072, 676);
+    run_setwg<4, true>((const float *)d, out, "UN4 nt G26", 3072, 676);
+    run_planes<2, true>((const float *)d, out, "UN2 nt G80", 384, 6400);
+    run_planes<2, true>((const float *)d, out, "UN2 nt G40", 1536, 1600);
+    run_planes<2, true>((const float *)d, out, "UN2 nt G20", 6144, 400);
     for (int blocks : {2048, 8192}) {
         run<1, false>(d, n, out, blocks, "UN1 plain");
         run<1, true>(d, n, out, blocks, "UN1 nt");

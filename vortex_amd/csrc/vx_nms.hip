@@ -585,7 +585,7 @@ struct vx_image_args {
     float *out_det;
     int *keep_counts, *status;
     int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
-    u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b (diagnostics, 8 stores per block)
+    u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
 };
 
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     const int npad = vx_next_pow2(n);
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
-#define VX_STAMP(k) do { if (threadIdx.x == 0) a.stamps[b * 8 + (k)] = clock64(); } while (0)
+#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * 8 + (k)] = clock64(); } while (0)
     VX_STAMP(0);
     bool bad = false;
     for (int i = threadIdx.x; i < npad; i += nt) {
@@ -815,7 +815,7 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
         a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.det = d_det; a.cls = (const long long *)d_cls;
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
-        a.status = d_status; a.stamps = w.stamps; a.seg = w.seg;
+        a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg;   // phase clocks only while profiling
         int threads = npad_cap >= 1024 ? 1024 : 256;
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
         hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)npad_cap * sizeof(u64), st, a);

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__rest
 // written.  Survivors are ballot-compacted inside the tile (order-preserving).
 struct vx_scale_desc {
     const float *ptr;
-    int G, cells, vec, tile_cells, tiles_per_plane;
+    int G, cells, tile_cells, tiles_per_plane;
     int tile_base;      // first tile index of this scale within an image
     int row_base;       // first output row of this scale
     float stride;
@@ -374,8 +374,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
 // no survivor is finished.  For each survivor the WAVE gathers the cell's 5+C channel values in one round trip
 // (lane = channel, stride = one plane), reduces (max sigmoid, first index) by butterfly and the owner lane
 // writes the record -- same arithmetic and same bits as the streaming tile.  HBM traffic: 1 plane + (5+C)
-// 128-B lines per survivor; tiles with more than p.sparse_max survivors (a quarter of it for 64-cell tiles)
-// return false and are streamed.
+// 128-B lines per survivor; tiles with more than p.sparse_max survivors return false and are streamed.
 // The NaN test covers every objectness value but the box/class values of surviving rows only (opt-in mode).
 template <int V>
 __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, const vx_scale_desc &s, int b, int a,
@@ -405,7 +404,7 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
         below += vx_mbcnt(m[j]);
         total += __popcll(m[j]);
     }
-    if (total > (V == 4 ? p.sparse_max : (p.sparse_max + 3) / 4)) return false;   // wave-uniform
+    if (total > p.sparse_max) return false;                                   // wave-uniform
     int mypos = below;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -462,9 +461,7 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec
     int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
     const vx_scale_desc &s = p.s[si];                 // wave-uniform
     if constexpr (SPARSE) {
-        if (s.vec ? vx_fused_tile_sparse<4>(p, s, b, a, cell0, row0, t, stage, tile_counts, status)
-                  : vx_fused_tile_sparse<1>(p, s, b, a, cell0, row0, t, stage, tile_counts, status))
-            return;
+        if (vx_fused_tile_sparse<4>(p, s, b, a, cell0, row0, t, stage, tile_counts, status)) return;
     }
     const bool partial = (s.cells & 3) != 0 && cell0 + s.tile_cells >= s.cells;   // wave-uniform: last tile of an odd plane
     if (partial) vx_fused_tile<4, UN, NT, true>(p, s, b, a, cell0, row0, t, stage, tile_counts, status);
@@ -618,8 +615,8 @@ static int vx_fused_setup(vx_fused_params &p, const float *h0, const float *h1, 
         s.G = S / div[i];
         if (s.G <= 0) return VX_ERR_INVALID_ARG;
         s.cells = s.G * s.G;
-        s.vec = 1;      // 16-B loads need dword alignment only (vx_v4u); a plane's last lane may own < 4 cells
-        s.tile_cells = s.vec ? 256 : 64;
+        s.tile_cells = 256;     // 64 lanes x 4 cells; 16-B loads need dword alignment only (vx_v4u), a plane's last
+                                // lane may own < 4 cells
         s.tiles_per_plane = (s.cells + s.tile_cells - 1) / s.tile_cells;
         s.tile_base = tile_base;
         s.row_base = row_base;
