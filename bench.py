@@ -256,6 +256,30 @@ def main():
             "decode_kernel_ms": round(kv.get("avg_ms", 0.0), 5),
             "note": "YoloV3FusedPostProcess(nan_check='survivors'): identical detections; NaN check covers objectness "
                     "and surviving rows only (deviation from postprocess/yolov3.py:35-36), hence not the headline"}
+        # the same variant replayed as one HIP graph (vortex_amd/graphs.py): at 0.15 ms of GPU work per step the
+        # ~0.09 ms of launch + allocation calls per eager step is what limits the line above
+        from vortex_amd.graphs import GraphedPostProcess
+        graphed = GraphedPostProcess(post, heads, sthr, ithr, preprocess=norm, images=img)
+
+        def graph_steps(n):
+            prev = None
+            for _ in range(n):
+                cur = graphed.launch()
+                if prev is not None:
+                    prev.result()
+                prev = cur
+            return prev.result()
+
+        graph_steps(3)
+        barrier()
+        t1 = time.perf_counter()
+        graph_steps(args.steps)
+        barrier()
+        dtg = time.perf_counter() - t1
+        variants["threshold_first_hipgraph"] = {
+            "value": round(B * args.steps / dtg, 1), "unit": "images/s", "ms_per_step": round(dtg / args.steps * 1e3, 4),
+            "note": "same kernels, pre-process + post-process captured once and replayed (fixed shapes and thresholds)"}
+        del graphed
         post = post_full
 
     if dist is not None:

@@ -131,3 +131,30 @@ def test_inference_helper_end_to_end():
     exp = O.adjust_coordinates(images, O.get_prediction_results(ref, FMT6), "relative")
     assert len(got) == n
     _same_results(got, exp)
+
+
+def test_graphed_postprocess_matches_eager_and_follows_its_inputs():
+    """HIP-graph replay (vortex_amd/graphs.py) == eager call, for the data present in the static input tensors at
+    replay time; results are copies (a later replay does not change them)."""
+    from vortex_amd.graphs import GraphedPostProcess
+    S, C, B = 416, 80, 3
+    st, it = torch.tensor([0.5]), torch.tensor([0.3])
+    h1 = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=61)]
+    h2 = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=62)]
+    img = O.synth_images(B, S, seed=5).to(DEV)
+    post, norm = V.YoloV3FusedPostProcess(S), V.Normalize().to(DEV)
+    static = [h.clone() for h in h1]
+    g = GraphedPostProcess(post, static, st, it, preprocess=norm, images=img)
+    r1, e1 = g(), post(h1, st, it)
+    assert len(r1) == B and all(torch.equal(a, b) for a, b in zip(r1, e1))
+    assert torch.equal(g.preprocessed, norm(img))
+    for s, h in zip(static, h2):
+        s.copy_(h)
+    r2, e2 = g(), post(h2, st, it)
+    assert all(torch.equal(a, b) for a, b in zip(r2, e2))
+    assert all(torch.equal(a, b) for a, b in zip(r1, e1))          # first results untouched by the second replay
+    # decoded-head (reference API boundary) variant
+    pred = O.yolo_head_eval(O.synth_yolo_heads(2, 64, C, seed=7), 64).to(DEV)
+    pp = V.YoloV3PostProcess(64)
+    g2 = GraphedPostProcess(pp, pred, 0.06, 0.2)
+    assert all(torch.equal(a, b) for a, b in zip(g2(), pp(pred, torch.tensor([0.06]), torch.tensor([0.2]))))

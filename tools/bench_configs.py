@@ -97,6 +97,9 @@ def yolo_b1():
         norm(img)
         return post(heads, st, it)
     run("yolov3_416_b1_latency", fn, 1, steps=200, warmup=20)
+    from vortex_amd.graphs import GraphedPostProcess
+    g = GraphedPostProcess(post, heads, st, it, preprocess=norm, images=img)
+    run("yolov3_416_b1_latency_hipgraph", lambda: g(), 1, steps=200, warmup=20)
 
 
 if __name__ == "__main__":
