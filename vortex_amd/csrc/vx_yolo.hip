@@ -136,78 +136,111 @@ struct vx_rows_params {
     int use_thr;
 };
 
+// Software-pipelined: a workgroup walks TPW consecutive tiles; the 16-B loads of tile j+1 are issued into
+// registers before tile j is reduced out of LDS, so HBM latency overlaps the class scan instead of preceding it.
+// A/B on MI355X, B=256, C=80 (tools/ab_unfused.py): TPW 1 / 2 / 4 / 8 = 4.77 / 5.55 / 4.30 / 3.94 TB/s.
+#define VX_K3_U 6
+template <int TPW>
 __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__restrict__ pred,
-                                                             vx_rec *__restrict__ stage,
-                                                             int *__restrict__ tile_counts,
-                                                             int *__restrict__ status, vx_rows_params p) {
+                                                               vx_rec *__restrict__ stage,
+                                                               int *__restrict__ tile_counts,
+                                                               int *__restrict__ status, vx_rows_params p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ float s_conf[64];
     __shared__ int s_cls[64];
-    int t = blockIdx.x % p.tiles_per_img, b = blockIdx.x / p.tiles_per_img;
-    int row0 = t * 64;
-    int nrow = min(64, p.R - row0);
+    const int groups_per_img = (p.tiles_per_img + TPW - 1) / TPW;
+    const int b = blockIdx.x / groups_per_img, t_first = (blockIdx.x % groups_per_img) * TPW;
     const int NP = p.NP;
-    long long o0 = ((long long)b * p.R + row0) * NP;
-    int shift = (int)(o0 & 3);
-    int n = nrow * NP;
-    int nchunk = (shift + n + 3) >> 2;
-    const float *gbase = pred + (o0 - shift);
     bool nan = false;
-    for (int k = threadIdx.x; k < nchunk; k += 256) {
-        int i = k * 4;
-        if (i >= shift && i + 4 <= shift + n) {
-            vx_v4 v = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(gbase + i));
-            nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-            *reinterpret_cast<vx_v4 *>(tile + i) = v;
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (i + j >= shift && i + j < shift + n) {
-                    float v = gbase[i + j];
-                    nan |= (v != v);
-                    tile[i + j] = v;
-                }
+    vx_v4 v[VX_K3_U];
+    bool full[VX_K3_U];
+    int shift = 0, n = 0, nchunk = 0;
+    const float *gbase = pred;
+
+    auto geometry = [&](int t) {
+        int row0 = t * 64;
+        int nrow = min(64, p.R - row0);
+        long long o0 = ((long long)b * p.R + row0) * NP;
+        shift = (int)(o0 & 3);
+        n = nrow * NP;
+        nchunk = (shift + n + 3) >> 2;
+        gbase = pred + (o0 - shift);
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int u = 0; u < VX_K3_U; ++u) {
+            int k = threadIdx.x + u * 256, i = k * 4;
+            full[u] = k < nchunk && i >= shift && i + 4 <= shift + n;
+            if (full[u]) v[u] = __builtin_nontemporal_load(reinterpret_cast<const vx_v4 *>(gbase + i));
         }
-    }
-    if (__ballot(nan) != 0 && vx_lane() == 0) atomicOr(status, VX_STATUS_NAN);
-    __syncthreads();
-    // class max / argmax: 4 lanes per row, interleaved classes, first max wins
-    {
-        int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        if (r < nrow) {
-            const float *row = tile + shift + r * NP + 5;
-            for (int k = q; k < p.C; k += 4) {
-                float v = row[k];
-                if (v > best || bi == 0x7fffffff) { best = v; bi = k; }
+    };
+
+    geometry(t_first);
+    issue();
+    for (int j = 0; j < TPW; ++j) {
+        const int t = t_first + j;
+        if (t >= p.tiles_per_img) break;
+        const int row0 = t * 64, nrow = min(64, p.R - row0);
+        const int cshift = shift;
+        // registers -> LDS (edge chunks and rows beyond VX_K3_U*1024 floats: scalar path)
+#pragma unroll
+        for (int u = 0; u < VX_K3_U; ++u) {
+            int k = threadIdx.x + u * 256, i = k * 4;
+            if (full[u]) {
+                nan |= (v[u].x != v[u].x) | (v[u].y != v[u].y) | (v[u].z != v[u].z) | (v[u].w != v[u].w);
+                *reinterpret_cast<vx_v4 *>(tile + i) = v[u];
+            } else if (k < nchunk) {
+                for (int q = 0; q < 4; ++q)
+                    if (i + q >= shift && i + q < shift + n) { float x = gbase[i + q]; nan |= (x != x); tile[i + q] = x; }
             }
         }
+        for (int k = threadIdx.x + VX_K3_U * 256; k < nchunk; k += 256) {
+            int i = k * 4;
+            for (int q = 0; q < 4; ++q)
+                if (i + q >= shift && i + q < shift + n) { float x = gbase[i + q]; nan |= (x != x); tile[i + q] = x; }
+        }
+        __syncthreads();
+        if (j + 1 < TPW && t + 1 < p.tiles_per_img) { geometry(t + 1); issue(); }     // next tile in flight
+        {
+            int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            if (r < nrow) {
+                const float *row = tile + cshift + r * NP + 5;
+                for (int k = q; k < p.C; k += 4) {
+                    float x = row[k];
+                    if (x > best || bi == 0x7fffffff) { best = x; bi = k; }
+                }
+            }
 #pragma unroll
-        for (int m = 1; m <= 2; m <<= 1) {
-            float ob = __shfl_xor(best, m);
-            int oi = __shfl_xor(bi, m);
-            if (ob > best || (ob == best && oi < bi) || (bi == 0x7fffffff && oi != 0x7fffffff)) { best = ob; bi = oi; }
+            for (int m = 1; m <= 2; m <<= 1) {
+                float ob = __shfl_xor(best, m);
+                int oi = __shfl_xor(bi, m);
+                if (ob > best || (ob == best && oi < bi) || (bi == 0x7fffffff && oi != 0x7fffffff)) { best = ob; bi = oi; }
+            }
+            if (q == 0 && r < nrow) { s_conf[r] = best; s_cls[r] = bi; }
         }
-        if (q == 0 && r < nrow) { s_conf[r] = best; s_cls[r] = bi; }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            int r = threadIdx.x;
+            bool pass = false;
+            float obj = 0.f;
+            const float *row = tile + cshift + r * NP;
+            if (r < nrow) {
+                obj = row[4];
+                pass = p.use_thr ? (obj > p.thr) : true;
+            }
+            u64 m = __ballot(pass);
+            if (pass) {
+                int pos = vx_mbcnt(m);
+                stage[(long long)b * p.R + row0 + pos] =
+                    vx_yolo_record(row[0], row[1], row[2], row[3], obj, s_conf[r], s_cls[r], row0 + r, p.img_size);
+            }
+            if (r == 0) tile_counts[(long long)b * p.tiles_per_img + t] = __popcll(m);
+        }
+        __syncthreads();                                   // LDS is rewritten by the next tile
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int r = threadIdx.x;
-        bool pass = false;
-        float obj = 0.f;
-        const float *row = tile + shift + r * NP;
-        if (r < nrow) {
-            obj = row[4];
-            pass = p.use_thr ? (obj > p.thr) : true;          // postprocess/yolov3.py:44 (strict, objectness only)
-        }
-        u64 m = __ballot(pass);
-        if (pass) {
-            int pos = vx_mbcnt(m);
-            vx_rec rec = vx_yolo_record(row[0], row[1], row[2], row[3], obj, s_conf[r], s_cls[r], row0 + r, p.img_size);
-            stage[(long long)b * p.R + row0 + pos] = rec;
-        }
-        if (r == 0) tile_counts[(long long)b * p.tiles_per_img + t] = __popcll(m);
-    }
+    if (__ballot(nan) != 0 && vx_lane() == 0) atomicOr(status, VX_STATUS_NAN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,7 +627,7 @@ extern "C" int vx_yolo_decode(const float *d_pred, int B, int R, int C, float im
     p.img_size = img_size; p.thr = score_threshold; p.use_thr = use_threshold ? 1 : 0;
     size_t lds = (size_t)(64 * NP + 4) * sizeof(float);
     vx_prof_begin(VX_PROF_DECODE_ROWS, st);
-    hipLaunchKernelGGL(vx_k_yolo_decode_rows, dim3((unsigned)(B * tiles)), dim3(256), lds, st, d_pred, stage,
+    hipLaunchKernelGGL(vx_k_yolo_decode_rows<2>, dim3((unsigned)(B * ((tiles + 1) / 2))), dim3(256), lds, st, d_pred, stage,
                        tile_counts, d_status, p);
     vx_prof_end(VX_PROF_DECODE_ROWS, st);
     vx_finish_params f;
