@@ -1,0 +1,129 @@
+"""Seeded fuzz parity: random sizes, class counts, thresholds and DEGENERATE inputs (ties, duplicates, zero-area and
+inverted boxes, quantised scores, ragged batches) through the C ABI against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import vortex_amd as V
+from vortex_amd import ops
+from oracle import vortex_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _boxes(kind, K, g):
+    if kind == "normal":
+        c, wh = torch.rand(K, 2, generator=g), torch.rand(K, 2, generator=g) * 0.3 + 0.01
+        return torch.cat((c - wh / 2, c + wh / 2), 1)
+    if kind == "grid":                                   # integer grid / 16: exact IoU ties at the threshold
+        xy = torch.randint(0, 12, (K, 2), generator=g).float() / 16
+        wh = torch.randint(0, 6, (K, 2), generator=g).float() / 16          # width 0 allowed: zero-area boxes
+        return torch.cat((xy, xy + wh), 1)
+    if kind == "dup":                                    # few distinct boxes repeated many times
+        base = _boxes("normal", max(1, K // 20), g)
+        return base[torch.randint(0, base.shape[0], (K,), generator=g)]
+    if kind == "inverted":                               # x2 < x1 for some boxes (negative width -> negative area)
+        b = _boxes("normal", K, g)
+        flip = torch.rand(K, generator=g) < 0.2
+        b[flip] = b[flip][:, [2, 1, 0, 3]]
+        return b
+    raise AssertionError(kind)
+
+
+def _case(seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    K = int(torch.randint(1, 3000, (1,), generator=g))
+    C = [1, 2, 5, 80, 1000, 4096][seed % 6]
+    kind = ["normal", "grid", "dup", "inverted"][seed % 4]
+    boxes = _boxes(kind, K, g).contiguous()
+    scores = torch.rand(K, generator=g)
+    if seed % 3 == 0:
+        scores = (scores * 8).floor() / 8                # heavy score ties: order decided by the index
+    cls = torch.randint(0, C, (K,), generator=g)
+    thr = [0.0, 0.1, 0.25, 0.3333333, 0.45, 0.5, 0.75, 1.0][seed % 8]
+    return boxes, scores, cls, thr
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_batched_nms(seed):
+    boxes, scores, cls, thr = _case(seed)
+    ref = O.batched_nms(boxes, scores, cls, torch.tensor([thr]))
+    got = V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([thr]))
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), (seed, thr, boxes.shape)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ragged_batch_with_top_k(seed):
+    """One launch, B images with different candidate counts (incl. 0 and 1) and a top_k; each image against the
+    oracle run on its own slice."""
+    g = torch.Generator().manual_seed(77 + seed)
+    B, cap, C = 9, 700, [3, 80][seed % 2]
+    counts = torch.randint(0, cap + 1, (B,), generator=g)
+    counts[0], counts[1], counts[2] = 0, 1, cap
+    boxes = torch.stack([_boxes(["normal", "grid", "dup"][b % 3], cap, g) for b in range(B)]).contiguous()
+    scores = torch.rand(B, cap, generator=g)
+    cls = torch.randint(0, C, (B, cap), generator=g)
+    det = torch.randn(B, cap, 7, generator=g)
+    top_k = [None, 50][seed % 2]
+    thr = [0.3, 0.5, 0.0][seed % 3]
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(torch.int32).to(DEV), thr, C, top_k)
+    assert int(status.item()) == 0
+    kc = keep_counts.cpu().tolist()
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([thr]))
+        if top_k is not None:
+            ref = ref[:top_k]
+        assert kc[b] == ref.numel(), (b, n)
+        assert torch.equal(keep_idx[b, :kc[b]].cpu(), ref)
+        assert torch.equal(out_det[b, :kc[b]].cpu(), det[b, :n][ref])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_yolo_postprocess(seed):
+    """Decoded-head boundary (bit-exact): random image size / class count / thresholds, rows with objectness exactly
+    at the threshold (strict '>'), all-below-threshold images."""
+    g = torch.Generator().manual_seed(300 + seed)
+    S = [64, 96, 128, 160][seed % 4]
+    C = [1, 3, 20, 80][(seed // 2) % 4]
+    B = 1 + seed % 3
+    pred = O.yolo_head_eval(O.synth_yolo_heads(B, S, C, seed=500 + seed), S)
+    sthr = [0.06, 0.5, 0.9, 0.0][seed % 4]
+    ithr = [0.2, 0.45, 1.0, 0.0][(seed // 3) % 4]
+    R = pred.shape[1]
+    idx = torch.randint(0, R, (R // 10,), generator=g)
+    pred[0, idx, 4] = sthr                               # exactly at the threshold: must be dropped
+    if B > 1:
+        pred[1, :, 4] = 0.0                              # nothing survives in image 1 (unless sthr < 0)
+    st, it = torch.tensor([sthr]), torch.tensor([ithr])
+    ref = O.yolo_postprocess(pred, st, it, S)
+    got = V.YoloV3PostProcess(S)(pred.to(DEV), st, it)
+    assert len(got) == B
+    for a, e in zip(got, ref):
+        assert a.shape == e.shape and torch.equal(a.cpu(), e)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_fused_decode_modes(seed):
+    """Raw-head boundary: streaming decode == threshold-first decode == YoloV3Layer x3 + decoder, bit for bit, for
+    odd grid sizes (G*G % 4 != 0), tiny and large class counts and thresholds from dense to empty."""
+    S = [32, 96, 160, 224, 416, 608, 352, 64, 480, 288][seed]
+    C = [1, 2, 7, 80, 80, 20, 243, 3, 5, 91][seed]      # 243 = the K2/K3 limit (5+C <= 248)
+    B = [3, 2, 2, 2, 1, 1, 1, 4, 1, 2][seed]
+    thr = [0.5, 0.06, 0.9, 0.3, 0.7, 0.95, 0.2, 0.0, 0.999, 0.5][seed]
+    heads = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=900 + seed)]
+    a = ops.yolo_fused_decode(heads, S, thr)
+    t = ops.yolo_fused_decode(heads, S, thr, threshold_first=True)
+    out = torch.empty((B, ops.yolo_rows(S), 5 + C), device=DEV)
+    off = 0
+    for h, mask in zip(heads, O.ANCHOR_MASKS):
+        G = h.shape[-1]
+        V.YoloV3Layer(S, (G, G), list(mask), O.COCO_ANCHORS, C).to(DEV).eval()(h, out=out, row_offset=off)
+        off += 3 * G * G
+    u = ops.yolo_decode(out, S, thr)
+    assert torch.equal(a.meta, t.meta) and torch.equal(a.meta, u.meta)
+    for b, k in enumerate(a.counts.cpu().tolist()):
+        for x, y, z in ((a.boxes, t.boxes, u.boxes), (a.scores, t.scores, u.scores), (a.cls, t.cls, u.cls), (a.det, t.det, u.det)):
+            assert torch.equal(x[b, :k], y[b, :k]) and torch.equal(x[b, :k], z[b, :k])
