@@ -588,6 +588,80 @@ struct vx_image_args {
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
 };
 
+// An image with <= 64 candidates (the common case at the shipped score threshold 0.9: ~10 per image) is one
+// wave's work: keys, both sorts (64-lane bitonic networks on shuffles), the greedy sweep and the outputs without
+// LDS or workgroup barriers.  Same keys, same IoU test, same ordering rules as the general path below.
+__device__ __forceinline__ u64 vx_wave_sort64(u64 key) {
+    const int lane = vx_lane();
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            u64 o = vx_shfl_xor_u64(key, j);
+            bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+            u64 mn = key < o ? key : o, mx = key < o ? o : key;
+            key = take_min ? mn : mx;
+        }
+    }
+    return key;
+}
+
+__device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b, int n) {
+    const vx_nms_params &p = a.p;
+    const int lane = vx_lane();
+    const long long ib = (long long)b * p.cap;
+    u64 key = VX_KEY_SENTINEL;
+    bool bad = false;
+    if (lane < n) {
+        long long c = a.cls[ib + lane];
+        if (c < 0 || c >= VX_MAX_CLASSES) { bad = true; c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
+        if (p.n_classes == 1 && c != 0) { bad = true; c = 0; }
+        key = vx_key1((int)c, a.scores[ib + lane], lane);
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
+    key = vx_wave_sort64(key);                       // (class, score desc, index); the n valid keys come first
+    const bool valid = lane < n;
+    vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
+    float ar = 0.f;
+    int cl = -1;
+    bool oob = false;
+    if (valid) {
+        cl = vx_key1_cls(key);
+        float off = (float)(cl * (VX_MAX_COORDINATE + 1));
+        bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
+        oob = !vx_box_in_range(bx);
+        bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
+        ar = (bx.z - bx.x) * (bx.w - bx.y);
+    }
+    if (p.n_classes != 1 && __ballot(oob) != 0 && lane == 0) atomicOr(a.status, VX_STATUS_RANGE);
+    const vx_thr T = vx_make_thr(p.thr);
+    u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    u64 todo = alive;
+    while (todo) {                                   // wave-uniform: next still-alive box in sorted order
+        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+        const float ix1 = vx_bcast(bx.x, i), iy1 = vx_bcast(bx.y, i), ix2 = vx_bcast(bx.z, i), iy2 = vx_bcast(bx.w, i);
+        const float ia = vx_bcast(ar, i);
+        const int ci = __builtin_amdgcn_readlane(cl, i);
+        bool sup = valid && lane > i && cl == ci && vx_iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, T);
+        alive &= ~__ballot(sup);
+        todo = alive & ~((2ull << i) - 1ull);
+    }
+    const bool kept = (alive >> lane) & 1ull;
+    u64 k2 = kept ? vx_key2_from_key1(key) : VX_KEY_SENTINEL;
+    k2 = vx_wave_sort64(k2);                         // kept boxes of all classes back into score order
+    int nk = __popcll(alive);
+    if (p.top_k > 0) nk = min(nk, p.top_k);
+    nk = min(nk, p.out_cap);
+    if (lane == 0) a.keep_counts[b] = nk;
+    if (lane < nk) {
+        const int idx = (int)(k2 & 0xFFFFFFFFull);
+        a.keep_idx[(long long)b * p.out_cap + lane] = (long long)idx;
+        const float *src = a.det + (ib + idx) * p.D;
+        float *dst = a.out_det + ((long long)b * p.out_cap + lane) * p.D;
+        for (int q = 0; q < p.D; ++q) dst[q] = src[q];
+    }
+}
+
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_sweep_smem_image S;
@@ -601,6 +675,10 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
     if (n == 0) {
         if (threadIdx.x == 0) a.keep_counts[b] = 0;
+        return;
+    }
+    if (n <= 64) {                                   // before any barrier: waves 1.. leave, wave 0 needs none
+        if (threadIdx.x < 64) vx_nms_image_small(a, b, n);
         return;
     }
     const int npad = vx_next_pow2(n);
