@@ -83,8 +83,13 @@ def stress_cfg():
 
     def fn():
         return ops.batched_nms(boxes, scores, cls, det, None, 0.45, C, 300)
+    # NMS is not HBM-bound -> report pair evaluations.  Upper bound = sum over (image, class) of
+    # n_c (n_c - 1) / 2 (every pair of a class segment); the greedy sweep skips pairs whose first box is suppressed.
+    cnt = torch.zeros(B, C, device=dev).scatter_add_(1, cls, torch.ones_like(cls, dtype=torch.float32))
+    pairs = float((cnt * (cnt - 1) / 2).sum())
     run("nms_stress_100k_c80_b32_top300", fn, B,
-        extra=lambda out: {"kept_per_image_after_topk": float(out[2].float().mean())})
+        extra=lambda out: {"kept_per_image_after_topk": float(out[2].float().mean()),
+                           "class_pair_upper_bound_per_step": pairs})
 
 
 def yolo_b1():
