@@ -187,6 +187,22 @@ int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacit
                  float *d_dst, int32_t *d_total,
                  const int32_t *d_meta_src, int32_t *meta_dst, int n_meta, void *stream);
 
+/* ---------------------------------------------------------------- whole YOLOv3 post-process, one host call
+ * vx_yolo_fused_decode -> vx_batched_nms -> vx_pack_rows chained on `stream` (no allocation, no synchronisation):
+ * the batch-level equivalent of YoloV3PostProcess.forward (postprocess/yolov3.py:71-79 over
+ * base_postprocess.py:110-138) from the three raw head tensors.
+ *   d_packed f32[B*out_cap*6]: kept rows (x1,y1,x2,y2,class_conf,class) of image 0, then image 1, ...
+ *                              out_cap = min(top_k, R) when top_k > 0, else R = 3*sum(G_s^2)
+ *   d_meta   i32[2B+1]       : counts[B] | keep_counts[B] | status  (zeroed here; status bits as above)
+ *   meta_mirror (optional)   : the same 2B+1 words copied to this device-accessible address (pinned host memory)
+ * use_threshold takes the VX_DECODE_* bits.  The workspace holds every intermediate. */
+size_t vx_yolo_fused_postprocess_workspace_bytes(int B, int S, int top_k);
+int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2,
+                              int B, int S, int C, const float anchors_px[18],
+                              float score_threshold, int use_threshold, float iou_threshold, int top_k,
+                              float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------- result formatting
  * vx_pack_rows + the output_format column slicing of get_prediction_results (predictor/utils.py:11-33) /
  * BaseRuntime.__call__ (src/runtime/vortex/runtime/basic_runtime.py:103-111) + the relative->absolute

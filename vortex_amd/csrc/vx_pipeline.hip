@@ -1,0 +1,80 @@
+// One host call for the whole YOLOv3 post-process: fused head decode -> class-aware NMS -> packed rows
+// (+ the counts/status words mirrored for the host).  Replaces, in one call,
+//   YoloV3Layer x3 + concat   (heads/detection/yolov3.py:263-304, models/detection/yolov3.py:72-76)
+//   YoloV3Decoder             (postprocess/yolov3.py:29-68)
+//   BatchedNMS per image      (postprocess/utils/nms.py:57-123)
+//   the per-image loop + tuple of BatchedNMSPostProcess.forward (base_postprocess.py:131-138)
+// It only chains the library's own entry points on the caller's stream: no allocation, no synchronisation;
+// the caller supplies one workspace for every intermediate.  Saves the host ~4 marshalled calls and ~8 tensor
+// allocations per batch (the synchronous Python API is host-bound at 256 images per call).
+#include "vx_common.h"
+
+static inline size_t vx_al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct vx_pipe_ws {
+    char *fused; size_t fused_bytes;
+    float *boxes, *scores, *det, *out_det;
+    int64_t *cls, *keep_idx;
+    char *nms; size_t nms_bytes;
+    size_t total;
+};
+
+static vx_pipe_ws vx_pipe_carve(void *ws, int B, int S, int out_cap) {
+    vx_pipe_ws w = {};
+    int R = 0;
+    const int div[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) { int G = S / div[i]; R += 3 * G * G; }
+    char *p = (char *)ws;
+    size_t off = 0, n = (size_t)B * R, m = (size_t)B * out_cap;
+    w.fused_bytes = vx_yolo_fused_workspace_bytes(B, S);
+    w.nms_bytes = vx_batched_nms_workspace_bytes(B, R);
+    w.fused = p + off; off += vx_al(w.fused_bytes);
+    w.boxes = (float *)(p + off); off += vx_al(n * 4 * sizeof(float));
+    w.scores = (float *)(p + off); off += vx_al(n * sizeof(float));
+    w.cls = (int64_t *)(p + off); off += vx_al(n * sizeof(int64_t));
+    w.det = (float *)(p + off); off += vx_al(n * 6 * sizeof(float));
+    w.keep_idx = (int64_t *)(p + off); off += vx_al(m * sizeof(int64_t));
+    w.out_det = (float *)(p + off); off += vx_al(m * 6 * sizeof(float));
+    w.nms = p + off; off += vx_al(w.nms_bytes);
+    w.total = off;
+    return w;
+}
+
+static int vx_pipe_rows(int S) {
+    int R = 0;
+    const int div[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) { int G = S / div[i]; R += 3 * G * G; }
+    return R;
+}
+
+extern "C" size_t vx_yolo_fused_postprocess_workspace_bytes(int B, int S, int top_k) {
+    if (B <= 0 || S < 32) return 0;
+    int R = vx_pipe_rows(S);
+    if (R > VX_MAX_CANDIDATES) return 0;
+    int out_cap = top_k > 0 && top_k < R ? top_k : R;
+    return vx_pipe_carve(nullptr, B, S, out_cap).total;
+}
+
+extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                                         int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                                         float iou_threshold, int top_k, float *d_packed, int32_t *d_meta,
+                                         int32_t *meta_mirror, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!d_packed || !d_meta || !d_workspace) return VX_ERR_INVALID_ARG;
+    if (B <= 0 || S < 32 || C <= 0) return VX_ERR_INVALID_ARG;
+    if (((uintptr_t)d_workspace & 255) || ((uintptr_t)d_packed & 3) || ((uintptr_t)d_meta & 3)) return VX_ERR_ALIGNMENT;
+    const int R = vx_pipe_rows(S);
+    if (R > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
+    const int out_cap = top_k > 0 && top_k < R ? top_k : R;
+    vx_pipe_ws w = vx_pipe_carve(d_workspace, B, S, out_cap);
+    if (workspace_bytes < w.total) return VX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *counts = d_meta, *keep_counts = d_meta + B, *status = d_meta + 2 * B;
+    if (hipMemsetAsync(d_meta, 0, (size_t)(2 * B + 1) * sizeof(int32_t), st) != hipSuccess) return VX_ERR_LAUNCH;
+    int rc = vx_yolo_fused_decode(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, w.boxes,
+                                  w.scores, w.cls, w.det, counts, status, w.fused, w.fused_bytes, stream);
+    if (rc != VX_OK) return rc;
+    rc = vx_batched_nms(w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k, w.keep_idx, w.out_det,
+                        keep_counts, out_cap, status, w.nms, w.nms_bytes, stream);
+    if (rc != VX_OK) return rc;
+    return vx_pack_rows(w.out_det, keep_counts, B, out_cap, 6, d_packed, nullptr, d_meta, meta_mirror, 2 * B + 1, stream);
+}

@@ -172,6 +172,45 @@ def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_thresh
     return c
 
 
+_ANCHOR_CACHE = {}
+
+
+def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float, iou_threshold: float,
+                           use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False,
+                           top_k: Optional[int] = None):
+    """Raw heads -> (packed f32[B*out_cap, 6], meta i32[2B+1] on the device, pinned host mirror of meta) with ONE
+    library call (vx_yolo_fused_postprocess): decode, NMS and packing are chained on the current stream; wait
+    for an event recorded after this call before reading the mirror."""
+    assert len(heads) == 3
+    hs = []
+    for h, d in zip(heads, (32, 16, 8)):
+        L.require_cuda(h, "head")
+        assert h.dtype == torch.float32 and h.dim() == 4 and h.size(2) == img_size // d == h.size(3)
+        hs.append(h.contiguous())
+    B, ch = hs[0].shape[:2]
+    C = ch // 3 - 5
+    R = yolo_rows(img_size)
+    dev = hs[0].device
+    tk = int(top_k) if top_k else 0
+    out_cap = min(R, tk) if tk > 0 else R
+    key = tuple(tuple(a) for a in anchors)
+    f18 = _ANCHOR_CACHE.get(key)
+    if f18 is None:
+        f18 = _ANCHOR_CACHE[key] = L.f18([float(v) for a in anchors for v in a])
+    lib = L.lib()
+    nb = lib.vx_yolo_fused_postprocess_workspace_bytes(B, int(img_size), tk)
+    ws = _ws(nb, dev)
+    packed = torch.empty((B * out_cap, 6), dtype=torch.float32, device=dev)
+    meta = torch.empty((2 * B + 1,), dtype=torch.int32, device=dev)
+    host = torch.empty((2 * B + 1,), dtype=torch.int32, pin_memory=True)
+    rc = lib.vx_yolo_fused_postprocess(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C, f18,
+                                       float(score_threshold), int(bool(use_threshold)) | (2 if threshold_first else 0),
+                                       float(iou_threshold), tk, packed.data_ptr(), meta.data_ptr(), host.data_ptr(),
+                                       ws.data_ptr(), nb, L.stream_ptr(dev))
+    L.check(rc, "vx_yolo_fused_postprocess")
+    return packed, meta, host
+
+
 # --------------------------------------------------------------------------------------- K4
 def prior_decode(inp: torch.Tensor, priors: torch.Tensor, n_landmarks: int, score_threshold: float,
                  use_threshold: bool = True, variances=(0.1, 0.2)) -> Candidates:

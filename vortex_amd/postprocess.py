@@ -274,6 +274,14 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
     def n_classes_hint(self, input) -> int:
         return int(input[0].size(1)) // 3 - 5
 
+    def forward_async(self, input: Sequence[torch.Tensor], score_threshold, iou_threshold) -> "PendingDetections":
+        """One library call for decode + NMS + packing (vx_yolo_fused_postprocess)."""
+        d = self.decoder
+        packed, meta, host = ops.yolo_fused_postprocess(
+            input, int(d.img_size), _f(score_threshold), _f(iou_threshold), d.threshold, d.anchors,
+            threshold_first=(d.nan_check == "survivors"), top_k=self.top_k)
+        return PendingDetections(packed, meta, host)
+
     def forward(self, input: Sequence[torch.Tensor], score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         return self.forward_async(input, score_threshold, iou_threshold).result()
 
