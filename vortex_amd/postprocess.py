@@ -10,6 +10,7 @@ single D2H copy (the reference loops per image in Python).
 
 Build-side extensions (default off == reference behaviour): `top_k`, and YoloV3FusedPostProcess which
 takes the three raw head tensors and never materialises the decoded [B,R,5+C] tensor."""
+import collections
 from typing import Callable, Optional, Sequence, Tuple, Union
 
 import torch
@@ -213,6 +214,9 @@ def finish_results(packed: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tens
     return _split_results(packed, meta.cpu().tolist())
 
 
+_INFLIGHT = collections.deque()       # (event, pinned mirror, packed, meta) of calls whose GPU work may be pending
+
+
 class PendingDetections:
     """Result of forward_async: the counts travel to pinned host memory on the launch stream, an
     event marks their arrival; result() waits for that event only (not for later launches)."""
@@ -225,6 +229,11 @@ class PendingDetections:
         self._host = host
         self._event = torch.cuda.Event()
         self._event.record(torch.cuda.current_stream(meta.device))
+        # A KERNEL writes the pinned mirror, which torch's host allocator cannot know: keep the buffer (and the
+        # device tensors) referenced until the event has fired even if the caller drops this object early.
+        _INFLIGHT.append((self._event, host, packed, meta))
+        while _INFLIGHT and _INFLIGHT[0][0].query():
+            _INFLIGHT.popleft()
 
     @classmethod
     def packing(cls, out_det: torch.Tensor, keep_counts: torch.Tensor, meta: torch.Tensor) -> "PendingDetections":
