@@ -77,6 +77,7 @@ __device__ __forceinline__ u64 vx_key2_from_key1(u64 k) { return (((k >> 20) & 0
 struct vx_finish_params {
     int R, tiles_per_img, D, L;           // D = 6 + 2L floats per detection row
     int uniform_tile_rows;                // >0: row0(t) = t*uniform_tile_rows ; 0: fused YOLO tile table
+    int tiles_per_wg;                     // tiles packed by one workgroup of vx_k_cand_finish (set at launch)
 };
 int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int *tile_counts, int B,
                             vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,

@@ -533,12 +533,20 @@ __global__ __launch_bounds__(256) void vx_k_cand_finish(const vx_rec *__restrict
     __shared__ int s_off[257];
     __shared__ int s_row0[256];
     __shared__ int s_wave[4];
-    int b = blockIdx.x;
-    int running = 0;
-    for (int t0 = 0; t0 < p.tiles_per_img; t0 += 256) {
+    // workgroup (g, b) packs the records of tiles [g*TW, (g+1)*TW) of image b; the records of earlier tiles only
+    // enter through their total, which every workgroup sums for itself (a few hundred ints)
+    const int b = blockIdx.y, TW = p.tiles_per_wg;
+    const int t0 = blockIdx.x * TW;
+    int running;
+    {
+        int acc = 0;
+        for (int t = threadIdx.x; t < t0; t += 256) acc += tile_counts[(long long)b * p.tiles_per_img + t];
+        (void)vx_block_excl_scan256(acc, s_wave, running);
+    }
+    {
         int t = t0 + threadIdx.x;
         int c = 0, row0 = 0;
-        if (t < p.tiles_per_img) {
+        if (threadIdx.x < TW && t < p.tiles_per_img) {
             c = tile_counts[(long long)b * p.tiles_per_img + t];
             if (p.uniform_tile_rows > 0) row0 = t * p.uniform_tile_rows;
             else { int si, a, cell0; row0 = vx_fused_tile_row0(fp, t, si, a, cell0); }
@@ -572,18 +580,24 @@ __global__ __launch_bounds__(256) void vx_k_cand_finish(const vx_rec *__restrict
                 for (int q = 0; q < 2 * p.L; ++q) d[6 + q] = lm[q];
             }
         }
-        running += total;
-        __syncthreads();
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[b] = running + total;
     }
-    if (threadIdx.x == 0) counts[b] = running;
+}
+
+// 32 tiles (2048 .. 8192 rows) per workgroup: 7 workgroups per image for 50 400 priors, 2 for YOLOv3-416
+static inline dim3 vx_finish_grid(vx_finish_params &f, int B) {
+    f.tiles_per_wg = f.tiles_per_img < 32 ? f.tiles_per_img : 32;
+    return dim3((unsigned)((f.tiles_per_img + f.tiles_per_wg - 1) / f.tiles_per_wg), (unsigned)B);
 }
 
 int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int *tile_counts, int B,
                             vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,
                             int *counts, hipStream_t st) {
     vx_fused_params fp = {};
+    if (B > 65535) return VX_ERR_UNSUPPORTED;
+    const dim3 grid = vx_finish_grid(f, B);
     vx_prof_begin(VX_PROF_FINISH, st);
-    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, (const vx_rec *)stage, stage_lmk, tile_counts, fp,
+    hipLaunchKernelGGL(vx_k_cand_finish, grid, dim3(256), 0, st, (const vx_rec *)stage, stage_lmk, tile_counts, fp,
                        f, boxes, scores, cls, det, counts);
     vx_prof_end(VX_PROF_FINISH, st);
     return VX_OK;
@@ -632,7 +646,9 @@ extern "C" int vx_yolo_decode(const float *d_pred, int B, int R, int C, float im
     vx_prof_end(VX_PROF_DECODE_ROWS, st);
     vx_finish_params f;
     f.R = R; f.tiles_per_img = tiles; f.D = 6; f.L = 0; f.uniform_tile_rows = 64;
-    vx_internal_cand_finish(stage, nullptr, tile_counts, B, f, d_boxes, d_scores, (long long *)d_cls, d_det, d_counts, st);
+    int rc = vx_internal_cand_finish(stage, nullptr, tile_counts, B, f, d_boxes, d_scores, (long long *)d_cls, d_det,
+                                     d_counts, st);
+    if (rc != VX_OK) return rc;
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
 
@@ -701,7 +717,7 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
         !d_counts || !d_status || !d_workspace)
         return VX_ERR_INVALID_ARG;
     if (B <= 0 || S < 32 || C <= 0) return VX_ERR_INVALID_ARG;
-    if (C > VX_MAX_CLASSES) return VX_ERR_UNSUPPORTED;
+    if (C > VX_MAX_CLASSES || B > 65535) return VX_ERR_UNSUPPORTED;
     if (((uintptr_t)d_head0 & 3) || ((uintptr_t)d_head1 & 3) || ((uintptr_t)d_head2 & 3) ||
         ((uintptr_t)d_boxes & 15) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_det & 3) ||
         ((uintptr_t)d_cls & 7))
@@ -739,7 +755,7 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     vx_finish_params f;
     f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;
     vx_prof_begin(VX_PROF_FINISH, st);
-    hipLaunchKernelGGL(vx_k_cand_finish, dim3(B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, p, f,
+    hipLaunchKernelGGL(vx_k_cand_finish, vx_finish_grid(f, B), dim3(256), 0, st, stage, (const float *)nullptr, tile_counts, p, f,
                        d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
     vx_prof_end(VX_PROF_FINISH, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
