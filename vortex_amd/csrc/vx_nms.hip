@@ -936,15 +936,19 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
 // ------------------------------------------------------------------------------------------------
 // Tuple packing (the `tuple(results)` of base_postprocess.py:131-138 without B Python slices):
 // rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
+#define VX_PACK_ROWS 2048
 __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ src, const int *__restrict__ counts,
                                                       int B, int cap, int D, float *__restrict__ dst,
                                                       int *__restrict__ total, const int *__restrict__ meta_src,
                                                       int *__restrict__ meta_dst, int n_meta) {
     __shared__ int s_part[256];
-    const int b = blockIdx.x;
+    // workgroup (g, b) copies rows [g*VX_PACK_ROWS, (g+1)*VX_PACK_ROWS) of image b; most leave at once
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int n = min(counts[b], cap);
+    if (g > 0 && g * VX_PACK_ROWS >= n) return;
     // the counts / status words of the call chain, mirrored for the host (meta_dst may be pinned host memory:
     // plain stores, visible after the stream's next event) so the path needs no D2H memcpy
-    if (b == 0 && meta_dst)
+    if (b == 0 && g == 0 && meta_dst)
         for (int i = threadIdx.x; i < n_meta; i += 256) meta_dst[i] = meta_src[i];
     int acc = 0;
     for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
@@ -955,11 +959,11 @@ __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ 
         __syncthreads();
     }
     const long long off = s_part[0];
-    const int n = min(counts[b], cap);
-    if (b == B - 1 && threadIdx.x == 0 && total) *total = (int)off + n;
-    const float *s = src + (long long)b * cap * D;
-    float *d = dst + off * D;
-    for (int i = threadIdx.x; i < n * D; i += 256) d[i] = s[i];
+    if (b == B - 1 && g == 0 && threadIdx.x == 0 && total) *total = (int)off + n;
+    const int r0 = g * VX_PACK_ROWS, r1 = min(n, r0 + VX_PACK_ROWS);
+    const float *s = src + ((long long)b * cap + r0) * D;
+    float *d = dst + (off + r0) * D;
+    for (int i = threadIdx.x; i < (r1 - r0) * D; i += 256) d[i] = s[i];
 }
 
 extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D, float *d_dst,
@@ -967,10 +971,11 @@ extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, 
     if (!d_src || !d_counts || !d_dst) return VX_ERR_INVALID_ARG;
     if (B <= 0 || capacity <= 0 || D <= 0) return VX_ERR_INVALID_ARG;
     if (meta_dst && (!d_meta_src || n_meta <= 0)) return VX_ERR_INVALID_ARG;
+    if (B > 65535) return VX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_PACK, st);
-    hipLaunchKernelGGL(vx_k_pack_rows, dim3(B), dim3(256), 0, st, d_src, d_counts, B, capacity, D, d_dst, d_total,
-                       d_meta_src, meta_dst, n_meta);
+    hipLaunchKernelGGL(vx_k_pack_rows, dim3((capacity + VX_PACK_ROWS - 1) / VX_PACK_ROWS, B), dim3(256), 0, st, d_src,
+                       d_counts, B, capacity, D, d_dst, d_total, d_meta_src, meta_dst, n_meta);
     vx_prof_end(VX_PROF_PACK, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
