@@ -963,7 +963,16 @@ __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ 
     const int r0 = g * VX_PACK_ROWS, r1 = min(n, r0 + VX_PACK_ROWS);
     const float *s = src + ((long long)b * cap + r0) * D;
     float *d = dst + (off + r0) * D;
-    for (int i = threadIdx.x; i < (r1 - r0) * D; i += 256) d[i] = s[i];
+    // final output, read by the host side only: non-temporal stores keep it from displacing the next batch's streams
+    const int nf = (r1 - r0) * D;
+    if ((((uintptr_t)s | (uintptr_t)d) & 7) == 0) {
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        for (int i = threadIdx.x; i < (nf >> 1); i += 256)
+            __builtin_nontemporal_store(reinterpret_cast<const v2 *>(s)[i], reinterpret_cast<v2 *>(d) + i);
+        if ((nf & 1) && threadIdx.x == 0) d[nf - 1] = s[nf - 1];
+    } else {
+        for (int i = threadIdx.x; i < nf; i += 256) __builtin_nontemporal_store(s[i], d + i);
+    }
 }
 
 extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacity, int D, float *d_dst,
