@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else 0.9
 sparse = len(sys.argv) > 2 and sys.argv[2] == "sparse"
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 416
-B, C = 256, 80
+B, C = int(os.environ.get('VX_AB_B', '256')), 80
 g = torch.Generator(device=dev).manual_seed(1234)
 heads = []
 for G in (S // 32, S // 16, S // 8):
@@ -30,6 +30,6 @@ for _ in range(100):
 torch.cuda.synchronize()
 k = L.profile_read()["vx_k_yolo_fused"]
 gb = B * ops.yolo_rows(S) * (5 + C) * 4 / 1e9
-print("%s S=%d thr %g (%d candidates) variant %s: avg %.4f ms  min %.4f ms  -> %.0f GB/s algorithmic" % (
+print("B=%d " % B + "%s S=%d thr %g (%d candidates) variant %s: avg %.4f ms  min %.4f ms  -> %.0f GB/s algorithmic" % (
     "threshold-first" if sparse else "streaming", S, thr, int(c.counts.sum()), os.environ.get("VX_FUSED_VARIANT", "-"),
     k["avg_ms"], k["min_ms"], gb / k["avg_ms"] * 1e3))

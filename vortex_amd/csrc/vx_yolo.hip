@@ -403,6 +403,112 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
     if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
 }
 
+// Small batches (fewer tiles than the GPU has wave slots): one wave per tile leaves the kernel bound by a single
+// wave's 85-plane sigmoid chain (19.8 us at B=1).  Here a workgroup of 4 waves shares ONE tile: wave w scans the
+// classes [w*C/4, (w+1)*C/4), the partial (max sigmoid, first index) pairs meet in LDS and wave 0 merges them in class
+// order (strict '>' keeps the first maximum) and finishes the tile exactly as vx_fused_tile does.  Same bits out.
+#define VX_SPLIT_WAVES 4
+#define VX_SPLIT_MAX_TILES 3584       // up to 14 tiles per CU (B <= 79 at 416): A/B split vs one wave per tile, us at B = 1/16/32/64/96/128: 10/16/26/41/61/82 vs 22/36/41/47/59/75
+__global__ __launch_bounds__(256) void vx_k_yolo_fused_split(vx_fused_params p, vx_rec *__restrict__ stage,
+                                                             int *__restrict__ tile_counts, int *__restrict__ status) {
+    constexpr int V = 4;
+    __shared__ float s_best[VX_SPLIT_WAVES][VX_WAVE * V];
+    __shared__ int s_bi[VX_SPLIT_WAVES][VX_WAVE * V];
+    const int b = blockIdx.x / p.tiles_per_img, t = blockIdx.x - b * p.tiles_per_img;
+    const int lane = vx_lane(), w = threadIdx.x >> 6;
+    int si, a, cell0;
+    const int row0 = vx_fused_tile_row0(p, t, si, a, cell0);
+    const vx_scale_desc &s = p.s[si];
+    const int c0 = cell0 + lane * V;
+    const int nv = min(max(s.cells - c0, 0), V);
+    const bool live = nv > 0;
+    const long long cells = s.cells;
+    const float *plane = s.ptr + ((long long)(b * 3 + a) * p.NP) * cells + c0;
+    const int kb = (int)((long long)p.C * w / VX_SPLIT_WAVES), ke = (int)((long long)p.C * (w + 1) / VX_SPLIT_WAVES);
+    float best[V];
+    int bi[V];
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = kb; }
+    vx_cells<V> tb[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch)
+#pragma unroll
+        for (int j = 0; j < V; ++j) tb[ch].v[j] = 0.f;
+    if (live) {
+        if (w == 0) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ++ch) {
+                tb[ch] = vx_load_cells<V, false>(plane + (long long)ch * cells, nv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) nan |= (tb[ch].v[j] != tb[ch].v[j]);
+            }
+        }
+        const float *cp = plane + 5 * cells;
+        constexpr int U = 4;
+        for (int k0 = kb; k0 < ke; k0 += U) {
+            vx_cells<V> A[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < ke) A[u] = vx_load_cells<V, false>(cp + (long long)(k0 + u) * cells, nv);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u;
+                if (k < ke) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        float v = A[u].v[j];
+                        nan |= (v != v);
+                        float sg = vx_sigmoid(v);
+                        if (sg > best[j] || k == kb) { best[j] = sg; bi[j] = k; }
+                    }
+                }
+            }
+        }
+    }
+    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s_best[w][lane * V + j] = best[j]; s_bi[w][lane * V + j] = bi[j]; }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int q = 1; q < VX_SPLIT_WAVES; ++q) {
+        if ((int)((long long)p.C * q / VX_SPLIT_WAVES) == (int)((long long)p.C * (q + 1) / VX_SPLIT_WAVES)) continue;   // empty class range
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float ob = s_best[q][lane * V + j];
+            if (ob > best[j]) { best[j] = ob; bi[j] = s_bi[q][lane * V + j]; }
+        }
+    }
+    float obj[V];
+    bool pass[V];
+    u64 m[V];
+    int below = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        obj[j] = live ? vx_sigmoid(tb[4].v[j]) : 0.f;
+        pass[j] = j < nv && (p.use_thr ? (obj[j] > p.thr) : true);
+        m[j] = __ballot(pass[j]);
+        below += vx_mbcnt(m[j]);
+        total += __popcll(m[j]);
+    }
+    int pos = below;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        if (pass[j]) {
+            int gc = c0 + j;
+            float cx = vx_yolo_xy(tb[0].v[j], (float)(gc % s.G), s.stride);
+            float cy = vx_yolo_xy(tb[1].v[j], (float)(gc / s.G), s.stride);
+            float bw = vx_yolo_wh(tb[2].v[j], s.aw[a], s.stride);
+            float bh = vx_yolo_wh(tb[3].v[j], s.ah[a], s.stride);
+            int row = row0 + lane * V + j;
+            stage[(long long)b * p.R + row0 + pos] = vx_yolo_record(cx, cy, bw, bh, obj[j], best[j], bi[j], row, p.img_size);
+            ++pos;
+        }
+    }
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + t] = total;
+}
+
 // "Threshold first" tile: the objectness plane is read first (coalesced, 1/(5+C) of the bytes); a tile with
 // no survivor is finished.  For each survivor the WAVE gathers the cell's 5+C channel values in one round trip
 // (lane = channel, stride = one plane), reduces (max sigmoid, first index) by butterfly and the owner lane
@@ -747,6 +853,9 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
     // without arithmetic 6.5 (2 planes in flight) .. 6.9 (12), linear read + sigmoid/max arithmetic 6.8.
     if (sparse)
         hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
+                           tile_counts, d_status);
+    else if (waves <= VX_SPLIT_MAX_TILES && C >= 2 * VX_SPLIT_WAVES)
+        hipLaunchKernelGGL(vx_k_yolo_fused_split, dim3((unsigned)waves), dim3(64 * VX_SPLIT_WAVES), 0, st, p, stage,
                            tile_counts, d_status);
     else
         hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
