@@ -451,3 +451,29 @@ def test_predictor_end_to_end_and_results():
     for a, b in zip(got, exp):
         for k in b:
             assert (a[k] is None and b[k] is None) or np.array_equal(a[k], b[k])
+
+
+# ------------------------------------------------------------------------------------------- secondary API surface
+def test_basic_postprocess_nonms_and_factories(golden):
+    """BasicNMSPostProcess (single image, base_postprocess.py:18-125) with and without NMS, the reference's factory
+    functions and NoOpPostProcess."""
+    g = golden("yolo_postprocess")
+    pred, S = T(g["pred"]), int(g["img_size"])
+    st, it = torch.tensor([0.06]), torch.tensor([0.2])
+    dec = V.YoloV3Decoder(img_size=S)
+    basic = V.BasicNMSPostProcess(decoder=dec, nms=True)
+    assert basic.additional_inputs == (("score_threshold", (1,)), ("iou_threshold", (1,)))
+    r = basic(pred[0:1], st, it)
+    assert r.dim() == 3 and r.size(0) == 1
+    same(r[0], g["post_p06_20_b0"])
+    nonms = V.BasicNMSPostProcess(decoder=dec, nms=False)
+    assert isinstance(nonms.nms, V.NoNMS)
+    det, bb, sc, ci = nonms(pred[0:1], st, it)                  # NoNMS returns the decoder's four outputs (nms.py:28)
+    same(det, g["dec_t06_b0_det"]); same(bb, g["dec_t06_b0_bboxes"]); same(sc, g["dec_t06_b0_scores"]); same(ci, g["dec_t06_b0_cls"])
+    pp = V.get_postprocess(img_size=S)                          # postprocess/yolov3.py:82-85
+    assert isinstance(pp, V.YoloV3PostProcess)
+    same(pp(pred, st, it)[1], g["post_p06_20_b1"])
+    x = torch.rand(2, 3, device=DEV)
+    assert V.NoOpPostProcess()(x, "ignored", k=1) is x
+    with pytest.raises(RuntimeError):                           # rank check of the decoder (postprocess/yolov3.py:37-39)
+        dec(pred[0], st)
