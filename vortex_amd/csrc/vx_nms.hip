@@ -70,6 +70,7 @@ struct vx_epi_params {
     // epilogue 1
     const float *boxes; vx_f4 *sbox; float *sarea; int cap;
     int *status; int guard;       // guard != 0: flag |coordinate| >= 1024 (see vx_box_in_range)
+    const int *sel;               // optional [B]: images with sel[b] == 0 were finished by vx_k_nms_image -> skip
     // epilogue 2
     const float *det; long long *keep_idx; float *out_det; int *keep_counts; int D, top_k, out_cap;
 };
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
                                                         vx_sort_params sp, vx_epi_params ep) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     const int b = blockIdx.y;
+    if (ep.sel && ep.sel[b] == 0) return;
     const int n = counts ? min(counts[b], sp.stride) : sp.fixed_n;
     const int npad = vx_next_pow2(max(n, 1));
     const int base = blockIdx.x * sp.CH;
@@ -585,6 +587,8 @@ struct vx_image_args {
     float *out_det;
     int *keep_counts, *status;
     int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
+    int *sel;         // optional [B]: out, n if the image has more than n_max candidates (left to the multi-kernel path) else 0
+    int n_max;
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
 };
 
@@ -673,6 +677,11 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const vx_nms_params &p = a.p;
     const int b = blockIdx.x, nt = blockDim.x;
     const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
+    if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
+        const bool big = n > a.n_max;
+        if (threadIdx.x == 0) a.sel[b] = big ? n : 0;
+        if (big) return;
+    }
     if (n == 0) {
         if (threadIdx.x == 0) a.keep_counts[b] = 0;
         return;
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
 // ------------------------------------------------------------------------------------------------
 static inline size_t vx_align256n(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; size_t bytes; };
+struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel; size_t bytes; };
 
 static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     vx_nms_ws w;
@@ -815,6 +824,7 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.count2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * 8 * sizeof(u64));   // per-image phase clocks (diagnostics)
     w.seg = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
+    w.sel = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.bytes = off;
     return w;
 }
@@ -878,8 +888,12 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     p.B = B; p.cap = capacity; p.npad_cap = npad_cap; p.D = D; p.n_classes = n_classes; p.top_k = top_k;
     p.out_cap = out_capacity; p.thr = iou_threshold;
 
-    if (npad_cap <= VX_SORT_CHMAX) {
-        // single-launch path: one workgroup per image, keys stay in LDS
+    // Single-launch path: one workgroup per image, keys stay in LDS.  With a capacity beyond the LDS-resident sort
+    // it still runs first and finishes every image that has at most VX_SORT_CHMAX candidates (the realistic case:
+    // a handful per image whatever the capacity); the multi-kernel path below then only works on the others
+    // (sel[b] = their count, 0 = done) -- for an all-small batch its launches find nothing to do.
+    const bool all_fit = npad_cap <= VX_SORT_CHMAX;
+    {
         static bool image_attr_set[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
@@ -894,12 +908,15 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg;   // phase clocks only while profiling
-        int threads = npad_cap >= 1024 ? 1024 : 256;
+        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX;
+        const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
+        int threads = lds_keys >= 1024 ? 1024 : 256;
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
-        hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)npad_cap * sizeof(u64), st, a);
+        hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)lds_keys * sizeof(u64), st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
-        return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+        if (all_fit) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
+    d_counts = w.sel;                                  // from here on: only the images the kernel above left
 
     vx_prof_begin(VX_PROF_NMS_KEYS, st);
     hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
@@ -907,7 +924,7 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     vx_prof_end(VX_PROF_NMS_KEYS, st);
     vx_epi_params ep = {};
     ep.boxes = d_boxes; ep.sbox = w.sbox; ep.sarea = w.sarea; ep.cap = capacity;
-    ep.status = d_status; ep.guard = n_classes != 1;
+    ep.status = d_status; ep.guard = n_classes != 1; ep.sel = w.sel;
     ep.det = d_det; ep.keep_idx = (long long *)d_keep_idx; ep.out_det = d_out_det; ep.keep_counts = d_keep_counts;
     ep.D = D; ep.top_k = top_k; ep.out_cap = out_capacity;
     vx_prof_begin(VX_PROF_SORT1, st);
