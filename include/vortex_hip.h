@@ -38,6 +38,8 @@ extern "C" {
 #define VX_STATUS_BAD_CLASS   2     /* class index outside [0, VX_MAX_CLASSES) (or != 0 when n_classes == 1) */
 #define VX_STATUS_RANGE       4     /* NMS: |box coordinate| >= 1024 with more than one class: the per-class
                                        sweep would differ from the reference's shifted single pass -> refused */
+#define VX_STATUS_DEFERRED    8     /* vx_batched_nms_small: some image had more candidates than the single-launch
+                                       kernel sorts (16384); repeat the call with vx_batched_nms */
 
 #define VX_MAX_CLASSES        4096  /* sort key holds the class in 12 bits               */
 #define VX_MAX_CANDIDATES     1048575 /* per image; sort key holds the index in 20 bits  */
@@ -175,6 +177,17 @@ int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d
  * Tolerance class (softmax/exp): 1e-5 relative on conf; boxes and labels exact. */
 int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_threshold,
                    float *d_out, int32_t *d_counts, void *stream);
+
+/* Optimistic variant of vx_batched_nms (same arguments, same results) for capacity > 16384: ONE launch; images
+ * with more than 16384 candidates are NOT processed, their keep count is 0 and VX_STATUS_DEFERRED is set in
+ * *d_status -- the caller checks the bit after synchronising and, if set, repeats the call with vx_batched_nms.
+ * No reference counterpart: it spares the launch-bound general path when candidates are few. */
+int vx_batched_nms_small(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
+                         const float *d_det, const int32_t *d_counts,
+                         int B, int capacity, int D, int n_classes, float iou_threshold, int top_k,
+                         int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
+                         int out_capacity, int32_t *d_status,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------- tuple packing
  * The `tuple(results)` of BatchedNMSPostProcess.forward (base_postprocess.py:131-138) as one launch:

@@ -15,6 +15,7 @@ VX_OK = 0
 VX_STATUS_NAN = 1
 VX_STATUS_BAD_CLASS = 2
 VX_STATUS_RANGE = 4
+VX_STATUS_DEFERRED = 8
 VX_MAX_CLASSES = 4096
 VX_MAX_CANDIDATES = 1048575
 VX_RESIZE_STRETCH = 0
@@ -52,6 +53,9 @@ _SIGNATURES = {
                                c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
     "vx_detr_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vx_batched_nms_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p]),
     "vx_format_results": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32),

@@ -589,6 +589,7 @@ struct vx_image_args {
     int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
     int *sel;         // optional [B]: out, n if the image has more than n_max candidates (left to the multi-kernel path) else 0
     int n_max;
+    int defer;        // != 0: such images are only reported (VX_STATUS_DEFERRED, keep_count 0), nobody finishes them
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
 };
 
@@ -679,7 +680,10 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
     if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
         const bool big = n > a.n_max;
-        if (threadIdx.x == 0) a.sel[b] = big ? n : 0;
+        if (threadIdx.x == 0) {
+            a.sel[b] = big ? n : 0;
+            if (big && a.defer) { atomicOr(a.status, VX_STATUS_DEFERRED); a.keep_counts[b] = 0; }
+        }
         if (big) return;
     }
     if (n == 0) {
@@ -863,11 +867,11 @@ static int vx_sort_launch(u64 *keys, const int *counts, int fixed_n, int B, int 
     return VX_OK;
 }
 
-extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
-                              const int32_t *d_counts, int B, int capacity, int D, int n_classes,
-                              float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
-                              int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
-                              size_t workspace_bytes, void *stream) {
+static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
+                       const int32_t *d_counts, int B, int capacity, int D, int n_classes,
+                       float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
+                       int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
+                       size_t workspace_bytes, void *stream, int small_only) {
     if (!d_boxes || !d_scores || !d_cls || !d_det || !d_keep_idx || !d_out_det || !d_keep_counts || !d_status ||
         !d_workspace)
         return VX_ERR_INVALID_ARG;
@@ -908,13 +912,13 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg;   // phase clocks only while profiling
-        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX;
+        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only;
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
         int threads = lds_keys >= 1024 ? 1024 : 256;
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
         hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)lds_keys * sizeof(u64), st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
-        if (all_fit) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+        if (all_fit || small_only) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
     d_counts = w.sel;                                  // from here on: only the images the kernel above left
 
@@ -948,6 +952,28 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
     vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
+                              const int32_t *d_counts, int B, int capacity, int D, int n_classes,
+                              float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
+                              int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
+                              size_t workspace_bytes, void *stream) {
+    return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
+                       d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, d_workspace, workspace_bytes, stream, 0);
+}
+
+// Optimistic variant for capacities beyond the single-launch kernel: ONE launch; an image with more than 16384
+// candidates is not processed but reported through VX_STATUS_DEFERRED (its keep count is 0) -- the caller then
+// repeats the call with vx_batched_nms.  Saves the ~12 launches of the general path, which find nothing to do
+// when every image is small (the normal case for prior-box models: capacity 50 400, a few candidates).
+extern "C" int vx_batched_nms_small(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
+                                    const int32_t *d_counts, int B, int capacity, int D, int n_classes,
+                                    float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
+                                    int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
+                       d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, d_workspace, workspace_bytes, stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

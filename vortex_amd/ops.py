@@ -14,6 +14,9 @@ COCO_ANCHORS = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45),
                 (59, 119), (116, 90), (156, 198), (373, 326)]   # reference networks/models/detection/yolov3.py:26-29
 
 
+NMS_SINGLE_LAUNCH_MAX = 16384      # candidates per image the single-launch NMS kernel sorts in LDS (VX_SORT_CHMAX)
+
+
 def yolo_rows(img_size: int) -> int:
     return 3 * sum((img_size // d) ** 2 for d in (32, 16, 8))
 
@@ -237,10 +240,12 @@ def prior_decode(inp: torch.Tensor, priors: torch.Tensor, n_landmarks: int, scor
 # --------------------------------------------------------------------------------------- K5-K7
 def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor, det: torch.Tensor,
                 counts: Optional[torch.Tensor], iou_threshold: float, n_classes: int = 0,
-                top_k: Optional[int] = None, meta: Optional[torch.Tensor] = None):
+                top_k: Optional[int] = None, meta: Optional[torch.Tensor] = None, optimistic: bool = False):
     """boxes f32[B,K,4], scores f32[B,K], cls i64[B,K], det f32[B,K,D], counts i32[B] or None.
     Returns keep_idx i64[B,out_cap], out_det f32[B,out_cap,D], keep_counts i32[B], status i32[1]
-    (device tensors; rows beyond keep_counts[b] are undefined)."""
+    (device tensors; rows beyond keep_counts[b] are undefined).
+    optimistic (K > 16384 only): one launch (vx_batched_nms_small); if an image has more than 16384 candidates the
+    status word carries VX_STATUS_DEFERRED and the call must be repeated without `optimistic`."""
     for t, n in ((boxes, "bboxes"), (scores, "scores"), (cls, "class_indexes"), (det, "detections")):
         L.require_cuda(t, n)
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and det.dtype == torch.float32
@@ -259,7 +264,8 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor, de
     keep_counts, status = meta[B:2 * B], meta[2 * B:]
     nb = L.lib().vx_batched_nms_workspace_bytes(B, K)
     ws = _ws(nb, dev)
-    rc = L.lib().vx_batched_nms(boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), det.data_ptr(),
+    fn = L.lib().vx_batched_nms_small if optimistic else L.lib().vx_batched_nms
+    rc = fn(boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), det.data_ptr(),
                                 counts.data_ptr() if counts is not None else None, B, K, D, int(n_classes),
                                 float(iou_threshold), tk, keep_idx.data_ptr(), out_det.data_ptr(),
                                 keep_counts.data_ptr(), out_cap, status.data_ptr(), ws.data_ptr(), nb,
@@ -268,9 +274,11 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor, de
     return keep_idx, out_det, keep_counts, status
 
 
-def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_k: Optional[int] = None):
+def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_k: Optional[int] = None,
+                   optimistic: bool = False):
     """decoder output -> NMS, sharing the meta words so one D2H copy reads counts, keep_counts, status."""
-    return batched_nms(c.boxes, c.scores, c.cls, c.det, c.counts, iou_threshold, n_classes, top_k, meta=c.meta)
+    return batched_nms(c.boxes, c.scores, c.cls, c.det, c.counts, iou_threshold, n_classes, top_k, meta=c.meta,
+                       optimistic=optimistic)
 
 
 def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor, meta: Optional[torch.Tensor] = None,
@@ -307,7 +315,7 @@ def detr_decode(inputs: torch.Tensor, score_threshold: float):
 
 
 def raise_on_status(status: int):
-    """Map device status bits to the reference's exceptions."""
+    """Map device status bits to the reference's exceptions (VX_STATUS_DEFERRED is not an error: see batched_nms)."""
     if status & L.VX_STATUS_NAN:
         # reference: networks/modules/postprocess/yolov3.py:35-36
         raise ValueError("your predictions have nan! please check")

@@ -188,8 +188,20 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         """Enqueue the whole post-process plus the D2H copy of the counts and return at once; the
         caller overlaps the next batch's launches with this one's GPU work and calls .result() later
         (serving loops).  forward() == forward_async().result()."""
-        out_det, keep_counts, meta = self.forward_unpacked(input, score_threshold, iou_threshold)
-        return PendingDetections.packing(out_det, keep_counts, meta)
+        c = self.decoder.decode_batch(input, score_threshold)
+        ithr, hint = _f(iou_threshold), self.n_classes_hint(input)
+        # capacity beyond the single-launch NMS kernel (prior-box models): bet on every image being small; the rare
+        # batch that is not comes back with VX_STATUS_DEFERRED and is redone by the general path in result()
+        optimistic = c.R > ops.NMS_SINGLE_LAUNCH_MAX
+        _, out_det, keep_counts, _ = ops.candidates_nms(c, ithr, hint, self.top_k, optimistic=optimistic)
+        pend = PendingDetections.packing(out_det, keep_counts, c.meta)
+        if optimistic:
+            def redo():
+                c.meta[2 * c.B:].bitwise_and_(~ops.L.VX_STATUS_DEFERRED)      # other status bits (NaN ...) stay
+                _, od, kc, _ = ops.candidates_nms(c, ithr, hint, self.top_k)
+                return PendingDetections.packing(od, kc, c.meta)
+            pend.redo = redo
+        return pend
 
     def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
@@ -242,9 +254,14 @@ class PendingDetections:
         host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
         return cls(ops.pack_rows(out_det, keep_counts, meta, host), meta, host)
 
+    redo = None          # set by callers that launched the optimistic NMS: () -> PendingDetections of the general path
+
     def result(self) -> Tuple[torch.Tensor, ...]:
         self._event.synchronize()
-        return _split_results(self.packed, self._host.tolist())
+        m = self._host.tolist()
+        if (m[-1] & ops.L.VX_STATUS_DEFERRED) and self.redo is not None:
+            return self.redo().result()
+        return _split_results(self.packed, m)
 
 
 class YoloV3PostProcess(BatchedNMSPostProcess):
