@@ -54,6 +54,8 @@ extern "C" {
  * covers every objectness value but the box/class values of surviving lanes only. */
 #define VX_DECODE_THRESHOLD       1
 #define VX_DECODE_THRESHOLD_FIRST 2
+/* vx_yolo_fused_postprocess only: run the NMS through vx_batched_nms_small (see there: VX_STATUS_DEFERRED) */
+#define VX_POSTPROCESS_NMS_OPTIMISTIC 4
 
 #define VX_RESIZE_STRETCH     0     /* src/runtime/vortex/runtime/basic_runtime.py:66-68 */
 #define VX_RESIZE_LETTERBOX   1     /* build-side extension (basic_runtime.py:70-73 is a TODO) */
@@ -208,7 +210,8 @@ int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacit
  *                              out_cap = min(top_k, R) when top_k > 0, else R = 3*sum(G_s^2)
  *   d_meta   i32[2B+1]       : counts[B] | keep_counts[B] | status  (zeroed here; status bits as above)
  *   meta_mirror (optional)   : the same 2B+1 words copied to this device-accessible address (pinned host memory)
- * use_threshold takes the VX_DECODE_* bits.  The workspace holds every intermediate. */
+ * use_threshold takes the VX_DECODE_* bits and VX_POSTPROCESS_NMS_OPTIMISTIC.  The workspace holds every
+ * intermediate. */
 size_t vx_yolo_fused_postprocess_workspace_bytes(int B, int S, int top_k);
 int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2,
                               int B, int S, int C, const float anchors_px[18],

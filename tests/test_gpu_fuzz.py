@@ -127,3 +127,24 @@ def test_fuzz_fused_decode_modes(seed):
     for b, k in enumerate(a.counts.cpu().tolist()):
         for x, y, z in ((a.boxes, t.boxes, u.boxes), (a.scores, t.scores, u.scores), (a.cls, t.cls, u.cls), (a.det, t.det, u.det)):
             assert torch.equal(x[b, :k], y[b, :k]) and torch.equal(x[b, :k], z[b, :k])
+
+
+def test_optimistic_nms_small_and_deferred_608():
+    """S=608: 22743 rows per image exceed the single-launch NMS kernel's 16384.  A sparse batch is finished by one
+    launch (vx_batched_nms_small); a batch with one dense image reports VX_STATUS_DEFERRED and is redone by the
+    general path -- both equal the layer-by-layer path and the oracle's NMS on the GPU's candidates."""
+    S, C, B = 608, 80, 2
+    heads = O.synth_yolo_heads(B, S, C, seed=77)
+    dheads = [h.to(DEV) for h in heads]
+    it = torch.tensor([0.45])
+    post = V.YoloV3FusedPostProcess(S)
+    for sthr, expect_deferred in ((0.9, False), (0.001, True)):
+        st = torch.tensor([sthr])
+        pend = post.forward_async(dheads, st, it)
+        res = pend.result()
+        deferred = bool(pend._host[-1].item() & V._lib.VX_STATUS_DEFERRED)
+        assert deferred == expect_deferred
+        c = ops.yolo_fused_decode(dheads, S, sthr)
+        for b, k in enumerate(c.counts.cpu().tolist()):
+            keep = O.batched_nms(c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu(), it)
+            assert torch.equal(res[b].cpu(), c.det[b, :k].cpu()[keep])

@@ -73,8 +73,11 @@ extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_he
     int rc = vx_yolo_fused_decode(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, w.boxes,
                                   w.scores, w.cls, w.det, counts, status, w.fused, w.fused_bytes, stream);
     if (rc != VX_OK) return rc;
-    rc = vx_batched_nms(w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k, w.keep_idx, w.out_det,
-                        keep_counts, out_cap, status, w.nms, w.nms_bytes, stream);
+    rc = (use_threshold & VX_POSTPROCESS_NMS_OPTIMISTIC)
+             ? vx_batched_nms_small(w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k, w.keep_idx,
+                                    w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream)
+             : vx_batched_nms(w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k, w.keep_idx,
+                              w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream);
     if (rc != VX_OK) return rc;
     return vx_pack_rows(w.out_det, keep_counts, B, out_cap, 6, d_packed, nullptr, d_meta, meta_mirror, 2 * B + 1, stream);
 }

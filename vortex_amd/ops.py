@@ -180,7 +180,7 @@ _ANCHOR_CACHE = {}
 
 def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float, iou_threshold: float,
                            use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False,
-                           top_k: Optional[int] = None):
+                           top_k: Optional[int] = None, optimistic_nms: bool = False):
     """Raw heads -> (packed f32[B*out_cap, 6], meta i32[2B+1] on the device, pinned host mirror of meta) with ONE
     library call (vx_yolo_fused_postprocess): decode, NMS and packing are chained on the current stream; wait
     for an event recorded after this call before reading the mirror."""
@@ -207,7 +207,8 @@ def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_t
     meta = torch.empty((2 * B + 1,), dtype=torch.int32, device=dev)
     host = torch.empty((2 * B + 1,), dtype=torch.int32, pin_memory=True)
     rc = lib.vx_yolo_fused_postprocess(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C, f18,
-                                       float(score_threshold), int(bool(use_threshold)) | (2 if threshold_first else 0),
+                                       float(score_threshold),
+                                       int(bool(use_threshold)) | (2 if threshold_first else 0) | (4 if optimistic_nms else 0),
                                        float(iou_threshold), tk, packed.data_ptr(), meta.data_ptr(), host.data_ptr(),
                                        ws.data_ptr(), nb, L.stream_ptr(dev))
     L.check(rc, "vx_yolo_fused_postprocess")

@@ -303,10 +303,20 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
     def forward_async(self, input: Sequence[torch.Tensor], score_threshold, iou_threshold) -> "PendingDetections":
         """One library call for decode + NMS + packing (vx_yolo_fused_postprocess)."""
         d = self.decoder
-        packed, meta, host = ops.yolo_fused_postprocess(
-            input, int(d.img_size), _f(score_threshold), _f(iou_threshold), d.threshold, d.anchors,
-            threshold_first=(d.nan_check == "survivors"), top_k=self.top_k)
-        return PendingDetections(packed, meta, host)
+        sthr, ithr = _f(score_threshold), _f(iou_threshold)
+
+        def call(optimistic):
+            packed, meta, host = ops.yolo_fused_postprocess(
+                input, int(d.img_size), sthr, ithr, d.threshold, d.anchors,
+                threshold_first=(d.nan_check == "survivors"), top_k=self.top_k, optimistic_nms=optimistic)
+            return PendingDetections(packed, meta, host)
+
+        # more rows per image than the single-launch NMS sorts (S >= 544): bet on few candidates, redo otherwise
+        optimistic = ops.yolo_rows(int(d.img_size)) > ops.NMS_SINGLE_LAUNCH_MAX
+        pend = call(optimistic)
+        if optimistic:
+            pend.redo = lambda: call(False)
+        return pend
 
     def forward(self, input: Sequence[torch.Tensor], score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
         return self.forward_async(input, score_threshold, iou_threshold).result()
