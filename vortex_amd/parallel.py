@@ -47,6 +47,9 @@ def allgather_detections(packed: torch.Tensor, meta_or_counts: torch.Tensor, B: 
     else:
         counts = meta_or_counts
         assert counts.numel() == B
+    if not (dist.is_available() and dist.is_initialized()):      # single process: nothing to gather
+        kc = counts.cpu().tolist()
+        return tuple(torch.split(packed[:sum(kc)], kc))
     world = dist.get_world_size(group)
     D = packed.size(1)
     all_counts = _all_gather_flat(counts.to(torch.int32), group).cpu()           # phase 1 (+ the D2H sync)
