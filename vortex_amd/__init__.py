@@ -12,6 +12,8 @@ reference's own nn.Module API for that path:
     detr.DETRPostProcess
     runtime.resize_batch / format_detections / adjust_coordinates / InferenceHelper
     parallel.shard_batch / allgather_detections
+    graphs.GraphedPostProcess            (HIP-graph replay for launch-bound batch sizes; import on demand)
+    export                               (torch.library custom ops + ONNX symbolic; import on demand)
 """
 from . import _lib, ops, runtime  # noqa: F401
 from .preprocess import Normalize, FlipNormalize, get_preprocess  # noqa: F401
