@@ -180,6 +180,13 @@ int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d
 int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_threshold,
                    float *d_out, int32_t *d_counts, void *stream);
 
+/* ---------------------------------------------------------------- classification post-process
+ * Replaces SoftmaxPostProcess.forward (networks/modules/postprocess/base_postprocess.py:140-150; caller
+ * networks/models/classification.py:98, output_format :45-49) for dim=1:
+ *   d_in f32[B,n_classes] logits -> d_out f32[B,2] = (float(first arg-max of softmax), max probability).
+ * Tolerance class (softmax/exp): 1e-5 relative on the probability; labels exact. */
+int vx_softmax_max(const float *d_in, int B, int n_classes, float *d_out, void *stream);
+
 /* Optimistic variant of vx_batched_nms (same arguments, same results) for capacity > 16384: ONE launch; images
  * with more than 16384 candidates are NOT processed, their keep count is 0 and VX_STATUS_DEFERRED is set in
  * *d_status -- the caller checks the bit after synchronising and, if set, repeats the call with vx_batched_nms.

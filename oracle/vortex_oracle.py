@@ -434,6 +434,15 @@ def synth_detr_outputs(B: int, Q: int = 100, n_logits: int = 92, seed: int = 0) 
     return torch.cat((box, lg), -1).contiguous()
 
 
+# --------------------------------------------------------------------------- classification post-process
+def softmax_postprocess(logits: torch.Tensor) -> torch.Tensor:
+    """SoftmaxPostProcess.forward with dim=1, keepdim=False (networks/modules/postprocess/base_postprocess.py:
+    147-150): softmax over the classes, max probability and its index -> [B,2] = (label as float, confidence)."""
+    p = torch.softmax(logits.float(), dim=1)
+    conf, label = p.max(dim=1)
+    return torch.stack((label.float(), conf), dim=1)
+
+
 # --------------------------------------------------------------------------- synthetic inputs (SURVEY.md §8d)
 def synth_images(B: int, S: int, seed: int = 0) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)

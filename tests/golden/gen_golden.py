@@ -63,6 +63,7 @@ from vortex.development.networks.modules.postprocess.yolov3 import YoloV3Decoder
 from vortex.development.networks.modules.postprocess.utils.nms import batched_nms, BatchedNMS  # noqa: E402
 from vortex.development.networks.modules.utils.darknet import yolo_feature_maps  # noqa: E402
 from vortex.development.networks.models.detection.detr import DETRPostProcess  # noqa: E402
+from vortex.development.networks.modules.postprocess.base_postprocess import SoftmaxPostProcess  # noqa: E402
 
 
 def np_(t):
@@ -201,8 +202,27 @@ def gen_detr():
     np.savez_compressed(os.path.join(HERE, "detr.npz"), **out)
 
 
+def gen_softmax():
+    """SoftmaxPostProcess of the reference (classification post-process) on seeded logits, incl. exact ties
+    (first index wins), a single class and a 1000-class head."""
+    pp = SoftmaxPostProcess()
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    for name, B, NC, scale in (("c10", 5, 10, 3.0), ("c1000", 4, 1000, 2.0), ("c1", 3, 1, 1.0), ("c65", 7, 65, 8.0)):
+        x = torch.randn(B, NC, generator=g) * scale
+        out["in_" + name], out["out_" + name] = np_(x), np_(pp(x))
+    x = torch.randn(6, 130, generator=g)
+    x[0, 5] = x[0, 77] = 9.0                      # exact tie across lanes
+    x[1, 64] = x[1, 0] = 7.5                      # exact tie inside one lane's stride
+    x[2] = 0.25                                   # every class equal
+    x[3, 129] = 30.0                              # last class, saturated
+    out["in_ties"], out["out_ties"] = np_(x), np_(pp(x))
+    np.savez_compressed(os.path.join(HERE, "softmax.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    gen_softmax()
     gen_detr()
     gen_normalize()
     gen_yolo_layer()

@@ -423,6 +423,39 @@ def test_detr_postprocess_reference_test_and_shapes(golden):
         _detr_check(x, 0.5, O.detr_postprocess(x, torch.tensor([0.5])))
 
 
+# ------------------------------------------------------------------------------------------- classification
+@pytest.mark.parametrize("name", ["c10", "c1000", "c1", "c65", "ties"])
+def test_softmax_postprocess_golden(golden, name):
+    """SoftmaxPostProcess (base_postprocess.py:140-150): labels exact (first index on exact ties), confidence
+    within 1e-5 rel of the reference's output."""
+    g = golden("softmax")
+    x = torch.from_numpy(g["in_" + name])
+    e = torch.from_numpy(g["out_" + name])
+    r = V.SoftmaxPostProcess().to(DEV)(x.to(DEV)).cpu()
+    assert r.dtype == torch.float32 and r.shape == e.shape == (x.shape[0], 2)
+    same(r[:, 0], e[:, 0]); close(r[:, 1], e[:, 1])
+
+
+def test_softmax_postprocess_shapes_and_errors():
+    g = torch.Generator().manual_seed(31)
+    for B, NC in ((1, 2), (257, 1000), (4096, 10), (3, 21843)):
+        x = torch.randn(B, NC, generator=g) * 4
+        e = O.softmax_postprocess(x)
+        r = V.SoftmaxPostProcess()(x.to(DEV)).cpu()
+        # a runner-up within the tolerance of the maximum may win the arg-max on either side
+        p = torch.softmax(x, 1).topk(min(2, NC), 1).values
+        clear = (p[:, 0] - p[:, -1]) > 2e-5 * p[:, 0] if NC > 1 else torch.ones(B, dtype=torch.bool)
+        assert clear.float().mean() > 0.99
+        same(r[clear, 0], e[clear, 0]); close(r[:, 1], e[:, 1])
+    k = V.SoftmaxPostProcess(keepdim=True)(torch.randn(5, 7, generator=g).to(DEV))
+    assert k.shape == (5, 2, 1)
+    assert V.SoftmaxPostProcess()(torch.zeros(0, 7, device=DEV)).shape == (0, 2)
+    with pytest.raises(RuntimeError):
+        V.SoftmaxPostProcess(dim=0)(torch.randn(5, 7).to(DEV))
+    with pytest.raises(RuntimeError):
+        V.SoftmaxPostProcess()(torch.randn(5, 7, 2).to(DEV))
+
+
 # ------------------------------------------------------------------------------------------- callers
 def test_predictor_end_to_end_and_results():
     """BasePredictor(preprocess -> model -> postprocess) with a stand-in model that returns a decoded head,

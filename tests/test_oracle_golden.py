@@ -189,3 +189,13 @@ def test_detr_reference_test_expectation(golden):
         assert torch.equal(exp, det[b])
     with pytest.raises(RuntimeError):
         O.detr_postprocess(x[0], torch.tensor(0.3))
+
+
+# --------------------------------------------------------------------------- classification post-process
+def test_softmax_oracle_equals_reference_golden(golden):
+    g = golden("softmax")
+    for name in ("c10", "c1000", "c1", "c65", "ties"):
+        out = O.softmax_postprocess(torch.from_numpy(g["in_" + name]))
+        assert torch.equal(out, torch.from_numpy(g["out_" + name])), name
+    t = g["out_ties"]
+    assert t[0, 0] == 5 and t[1, 0] == 0 and t[2, 0] == 0 and t[3, 0] == 129      # first index wins

@@ -6,7 +6,7 @@ reference's own nn.Module API for that path:
     preprocess.Normalize / FlipNormalize / get_preprocess
     heads.YoloV3Layer
     postprocess.YoloV3Decoder / BatchedNMS / NMS / NoNMS / BatchedNMSPostProcess /
-                YoloV3PostProcess / YoloV3FusedPostProcess
+                YoloV3PostProcess / YoloV3FusedPostProcess / SoftmaxPostProcess / NoOpPostProcess
     prior.PriorBoxDecoder / PriorBoxPostProcess
     predictor.BasePredictor / create_predictor / get_prediction_results
     detr.DETRPostProcess
@@ -20,7 +20,7 @@ from .preprocess import Normalize, FlipNormalize, get_preprocess  # noqa: F401
 from .heads import YoloV3Layer, yolo_feature_maps  # noqa: F401
 from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostProcess,  # noqa: F401
                           BatchedNMSPostProcess, YoloV3PostProcess, YoloV3FusedPostProcess,
-                          NoOpPostProcess, batched_nms, get_postprocess)
+                          NoOpPostProcess, SoftmaxPostProcess, batched_nms, get_postprocess)
 from .prior import PriorBoxDecoder, PriorBoxPostProcess  # noqa: F401
 from .detr import DETRPostProcess  # noqa: F401
 from .predictor import BasePredictor, create_predictor, get_prediction_results  # noqa: F401

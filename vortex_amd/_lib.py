@@ -53,6 +53,7 @@ _SIGNATURES = {
                                c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
     "vx_detr_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vx_softmax_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vx_batched_nms_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

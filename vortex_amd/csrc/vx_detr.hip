@@ -25,6 +25,30 @@ __device__ __forceinline__ float vx_wave_sum(float v) {
     return v;
 }
 
+// softmax over lg[0..n_all) followed by (max probability, first index) over lg[0..n_best); executed by a whole
+// wave, every lane returns the same bits.  Probabilities are exp(l - max) / sum as torch's softmax.
+__device__ __forceinline__ void vx_wave_softmax_best(const float *__restrict__ lg, int n_all, int n_best, int lane,
+                                                     float &p, int &pi) {
+    float m = -INFINITY;
+    for (int c = lane; c < n_all; c += VX_WAVE) m = fmaxf(m, lg[c]);
+    m = vx_wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < n_all; c += VX_WAVE) s += vx_exp(lg[c] - m);
+    s = vx_wave_sum(s);
+    p = -1.f;                                                 // probabilities are >= 0
+    pi = 0x7fffffff;
+    for (int c = lane; c < n_best; c += VX_WAVE) {
+        float q = vx_exp(lg[c] - m) / s;
+        if (q > p) { p = q; pi = c; }                         // first max within the lane (c ascending)
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {                       // (max p, lowest index) across lanes
+        float op = __shfl_xor(p, k, VX_WAVE);
+        int oi = __shfl_xor(pi, k, VX_WAVE);
+        if (op > p || (op == p && oi < pi)) { p = op; pi = oi; }
+    }
+}
+
 __global__ __launch_bounds__(VX_DETR_WAVES *VX_WAVE) void vx_k_detr_decode(
     const float *__restrict__ in, int Q, int NC1, float thr, float *__restrict__ out, int *__restrict__ counts) {
     __shared__ int s_wcnt[VX_DETR_WAVES];
@@ -46,24 +70,9 @@ __global__ __launch_bounds__(VX_DETR_WAVES *VX_WAVE) void vx_k_detr_decode(
         for (int i = 0; i < nrows; ++i) {
             const float *row = img + (size_t)(row0 + i) * ncol;
             const float *lg = row + 4;
-            float m = -INFINITY;
-            for (int c = lane; c < NC1; c += VX_WAVE) m = fmaxf(m, lg[c]);
-            m = vx_wave_max(m);
-            float s = 0.f;
-            for (int c = lane; c < NC1; c += VX_WAVE) s += vx_exp(lg[c] - m);
-            s = vx_wave_sum(s);
-            float p = -1.f;                                   // probabilities are >= 0
-            int pi = 0x7fffffff;
-            for (int c = lane; c < NC; c += VX_WAVE) {
-                float q = vx_exp(lg[c] - m) / s;
-                if (q > p) { p = q; pi = c; }                 // first max within the lane (c ascending)
-            }
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) {               // (max p, lowest index) across lanes
-                float op = __shfl_xor(p, k, VX_WAVE);
-                int oi = __shfl_xor(pi, k, VX_WAVE);
-                if (op > p || (op == p && oi < pi)) { p = op; pi = oi; }
-            }
+            float p;
+            int pi;
+            vx_wave_softmax_best(lg, NC1, NC, lane, p, pi);
             float v = lane < 4 ? row[lane] : 0.f;
             float cx = __shfl(v, 0, VX_WAVE), cy = __shfl(v, 1, VX_WAVE);
             float w = __shfl(v, 2, VX_WAVE), h = __shfl(v, 3, VX_WAVE);
@@ -107,5 +116,33 @@ extern "C" int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, flo
     hipLaunchKernelGGL(vx_k_detr_decode, dim3(B), dim3(VX_DETR_WAVES * VX_WAVE), 0, st, d_in, Q, n_logits,
                        score_threshold, d_out, d_counts);
     vx_prof_end(VX_PROF_DETR, st);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+// Classification post-process: softmax over the classes of a row, (first arg-max as float, max probability).
+// Follows SoftmaxPostProcess.forward (networks/modules/postprocess/base_postprocess.py:147-150) for dim=1:
+// out[b] = (float(label), conf).  One wave per row.
+__global__ __launch_bounds__(VX_DETR_WAVES *VX_WAVE) void vx_k_softmax_max(const float *__restrict__ in, int B, int NC,
+                                                                          float *__restrict__ out) {
+    const int row = blockIdx.x * VX_DETR_WAVES + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int lane = vx_lane();
+    float p;
+    int pi;
+    vx_wave_softmax_best(in + (size_t)row * NC, NC, NC, lane, p, pi);
+    if (lane == 0) {
+        out[2 * (size_t)row] = (float)pi;
+        out[2 * (size_t)row + 1] = p;
+    }
+}
+
+extern "C" int vx_softmax_max(const float *d_in, int B, int n_classes, float *d_out, void *stream) {
+    if (!d_in || !d_out || B <= 0 || n_classes <= 0) return VX_ERR_INVALID_ARG;
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 3) return VX_ERR_ALIGNMENT;
+    hipStream_t st = (hipStream_t)stream;
+    vx_prof_begin(VX_PROF_SOFTMAX, st);
+    hipLaunchKernelGGL(vx_k_softmax_max, dim3((unsigned)((B + VX_DETR_WAVES - 1) / VX_DETR_WAVES)),
+                       dim3(VX_DETR_WAVES * VX_WAVE), 0, st, d_in, B, n_classes, d_out);
+    vx_prof_end(VX_PROF_SOFTMAX, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }

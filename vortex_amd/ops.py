@@ -315,6 +315,18 @@ def detr_decode(inputs: torch.Tensor, score_threshold: float):
     return out, meta
 
 
+def softmax_max(logits: torch.Tensor) -> torch.Tensor:
+    """f32[B,NC] logits -> f32[B,2] = (float(first arg-max of softmax), max probability) (vx_softmax_max)."""
+    L.require_cuda(logits, "input")
+    x = logits.contiguous().float()
+    B, NC = x.shape
+    out = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    if B:
+        rc = L.lib().vx_softmax_max(x.data_ptr(), B, NC, out.data_ptr(), L.stream_ptr(x.device))
+        L.check(rc, "vx_softmax_max")
+    return out
+
+
 def raise_on_status(status: int):
     """Map device status bits to the reference's exceptions (VX_STATUS_DEFERRED is not an error: see batched_nms)."""
     if status & L.VX_STATUS_NAN:

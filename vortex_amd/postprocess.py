@@ -322,6 +322,25 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
         return self.forward_async(input, score_threshold, iou_threshold).result()
 
 
+class SoftmaxPostProcess(nn.Module):
+    """Classification post-process (base_postprocess.py:140-150): softmax over dim 1, then the maximum and
+    its (first) index -> f32[B,2] = (class_label, class_confidence), the layout classification.py:45-49
+    declares.  One launch (vx_softmax_max); the reference's other `dim` values reduce over the batch and
+    are refused."""
+
+    def __init__(self, dim=1, keepdim=False):
+        super(SoftmaxPostProcess, self).__init__()
+        self.dim = dim
+        self.keepdim = keepdim
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if input.ndim != 2 or self.dim not in (1, -1):
+            raise RuntimeError("SoftmaxPostProcess on the device handles [batch, classes] logits with dim=1, got "
+                               "shape %s dim=%s" % (tuple(input.shape), self.dim))
+        out = ops.softmax_max(input)
+        return out.unsqueeze(2) if self.keepdim else out
+
+
 class NoOpPostProcess(nn.Module):
     def __init__(self):
         super(NoOpPostProcess, self).__init__()
