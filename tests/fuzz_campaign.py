@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Time-bounded fuzz campaign (not collected by pytest): the seeded generators of test_gpu_fuzz.py over many more
+seeds and larger candidate counts (single-wave, single-launch and multi-kernel NMS paths), every result compared
+bit for bit with the CPU oracle.  Prints one progress line per 25 cases and a JSON summary.
+
+    python tests/fuzz_campaign.py [seconds=240] [first_seed=1000]
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import vortex_amd as V  # noqa: E402
+from vortex_amd import ops  # noqa: E402
+from oracle import vortex_oracle as O  # noqa: E402
+from tests.test_gpu_fuzz import _boxes  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def nms_case(seed):
+    g = torch.Generator().manual_seed(50_000 + seed)
+    hi = [64, 300, 3000, 17000, 40000][seed % 5]          # wave path / pair path / LDS path / edge of LDS / global sort
+    K = int(torch.randint(1, hi + 1, (1,), generator=g))
+    C = [1, 2, 5, 21, 80, 1000, 4096][seed % 7]
+    kind = ["normal", "grid", "dup", "inverted"][(seed // 5) % 4]
+    if kind in ("dup", "grid") and K > 6000:
+        K = 6000                                          # O(K^2) oracle on heavily overlapping boxes
+    boxes = _boxes(kind, K, g).contiguous()
+    scores = torch.rand(K, generator=g)
+    if seed % 3 == 0:
+        scores = (scores * 16).floor() / 16
+    cls = torch.randint(0, C, (K,), generator=g)
+    thr = [0.0, 0.1, 0.25, 0.3333333, 0.45, 0.5, 0.75, 1.0, 0.2, 0.6][seed % 10]
+    ref = O.batched_nms(boxes, scores, cls, torch.tensor([thr]))
+    got = V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([thr])).cpu()
+    return torch.equal(got, ref), dict(kind="nms", seed=seed, K=K, C=C, box=kind, thr=thr)
+
+
+def yolo_case(seed):
+    g = torch.Generator().manual_seed(60_000 + seed)
+    S = 32 * int(torch.randint(1, 11, (1,), generator=g))
+    C = [1, 2, 3, 7, 20, 80, 91][seed % 7]
+    B = 1 + seed % 4
+    sthr = [0.06, 0.5, 0.9, 0.0, 0.3, 0.97][seed % 6]
+    ithr = [0.2, 0.45, 1.0, 0.0, 0.6][seed % 5]
+    heads = O.synth_yolo_heads(B, S, C, seed=70_000 + seed)
+    pred = O.yolo_head_eval(heads, S)
+    st, it = torch.tensor([sthr]), torch.tensor([ithr])
+    # bit-exact boundary: decoded head -> decoder -> NMS
+    ref = O.yolo_postprocess(pred, st, it, S)
+    got = V.YoloV3PostProcess(S)(pred.to(DEV), st, it)
+    ok = len(got) == B and all(a.shape == e.shape and torch.equal(a.cpu(), e) for a, e in zip(got, ref))
+    # raw-head boundary: the three decode modes agree bit for bit, and the one-call pipeline equals NMS on them
+    dheads = [h.to(DEV) for h in heads]
+    a = ops.yolo_fused_decode(dheads, S, sthr)
+    t = ops.yolo_fused_decode(dheads, S, sthr, threshold_first=True)
+    ok = ok and torch.equal(a.meta, t.meta)
+    res = V.YoloV3FusedPostProcess(S)(dheads, st, it)
+    for b, k in enumerate(a.counts.cpu().tolist()):
+        ok = ok and torch.equal(a.det[b, :k], t.det[b, :k]) and torch.equal(a.scores[b, :k], t.scores[b, :k])
+        keep = O.batched_nms(a.boxes[b, :k].cpu(), a.scores[b, :k].cpu(), a.cls[b, :k].cpu(), it)
+        ok = ok and torch.equal(res[b].cpu(), a.det[b, :k].cpu()[keep])
+    return ok, dict(kind="yolo", seed=seed, S=S, C=C, B=B, sthr=sthr, ithr=ithr)
+
+
+def prior_case(seed):
+    g = torch.Generator().manual_seed(80_000 + seed)
+    P = int(torch.randint(1, 3000, (1,), generator=g))
+    Lm = [0, 5, 0, 2][seed % 4]
+    NL = [2, 2, 21, 4][seed % 4]
+    B = 1 + seed % 3
+    priors = torch.rand(P, 4, generator=g) * 0.5 + 0.05
+    x = O.synth_prior_head(B, P, Lm, NL, seed=90_000 + seed)
+    sthr = [0.5, 0.05, 0.9, 0.3][seed % 4]
+    st, it = torch.tensor([sthr]), torch.tensor([0.4])
+    pp = V.PriorBoxPostProcess(priors.to(DEV), n_landmarks=Lm).to(DEV)
+    got = pp(x.to(DEV), st, it)
+    # tolerance-class decode: compare the NMS on the GPU's own candidates with the oracle's NMS (bit-exact part)
+    c = pp.decoder.decode_batch(x.to(DEV), st) if hasattr(pp.decoder, "decode_batch") else None
+    ok = len(got) == B
+    if c is not None:
+        for b, k in enumerate(c.counts.cpu().tolist()):
+            keep = O.batched_nms(c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu(), it)
+            ok = ok and torch.equal(got[b].cpu(), c.det[b, :k].cpu()[keep])
+    return ok, dict(kind="prior", seed=seed, P=P, L=Lm, NL=NL, B=B, sthr=sthr)
+
+
+def ragged_case(seed):
+    """B images, counts from 0 to beyond the single-launch limit in ONE call (both NMS paths side by side), top_k."""
+    g = torch.Generator().manual_seed(110_000 + seed)
+    B = 2 + seed % 4
+    cap = [900, 5000, 17500, 24000][seed % 4]
+    C = [1, 3, 80, 4096][(seed // 4) % 4]
+    counts = torch.randint(0, cap + 1, (B,), generator=g)
+    counts[0] = cap
+    if B > 2:
+        counts[1] = 0
+    boxes = torch.stack([_boxes("normal", cap, g) for _ in range(B)]).contiguous()
+    scores = torch.rand(B, cap, generator=g)
+    cls = torch.randint(0, C, (B, cap), generator=g)
+    det = torch.randn(B, cap, 6, generator=g)
+    top_k = [None, 100, 1][seed % 3]
+    thr = [0.3, 0.5, 0.7][seed % 3]
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(torch.int32).to(DEV), thr, C, top_k)
+    ok = int(status.item()) == 0
+    kc = keep_counts.cpu().tolist()
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([thr]))
+        if top_k is not None:
+            ref = ref[:top_k]
+        ok = ok and kc[b] == ref.numel() and torch.equal(keep_idx[b, :kc[b]].cpu(), ref) \
+            and torch.equal(out_det[b, :kc[b]].cpu(), det[b, :n][ref])
+    return ok, dict(kind="ragged", seed=seed, B=B, cap=cap, C=C, top_k=top_k, thr=thr)
+
+
+def pre_case(seed):
+    """Normalize / FlipNormalize on arbitrary H, W (odd sizes, unaligned planes) and the u8 resize + fused
+    resize-normalize on arbitrary source / destination sizes, stretch and letterbox: bit-exact."""
+    import numpy as np
+    g = torch.Generator().manual_seed(120_000 + seed)
+    B = 1 + seed % 3
+    H, W = (int(v) for v in torch.randint(1, 200, (2,), generator=g))
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    mean = (torch.rand(3, generator=g)).tolist()
+    std = (torch.rand(3, generator=g) * 0.9 + 0.1).tolist()
+    flip = bool(seed & 1)
+    mod = (V.FlipNormalize if flip else V.Normalize)(mean, std).to(DEV)
+    ok = torch.equal(mod(img.to(DEV)).cpu(), O.normalize(img, mean, std, flip=flip))
+    oh, ow = (int(v) for v in torch.randint(1, 160, (2,), generator=g))
+    lb = bool(seed & 2)
+    ref = np.stack([O.resize_bilinear_u8(im, oh, ow, lb) for im in img.numpy()])
+    y = ops.resize_u8(img.to(DEV), (oh, ow), letterbox=lb).cpu().numpy()
+    ok = ok and np.array_equal(y, ref)
+    z = ops.preprocess(img.to(DEV), mean, std, 255, out_size=(oh, ow), letterbox=lb)
+    ok = ok and torch.equal(z.cpu(), O.normalize(torch.from_numpy(ref), mean, std))
+    return ok, dict(kind="pre", seed=seed, B=B, H=H, W=W, oh=oh, ow=ow, letterbox=lb, flip=flip)
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0, n, fails = time.time(), 0, []
+    per_kind = {"nms": 0, "yolo": 0, "prior": 0, "ragged": 0, "pre": 0}
+    seed = first
+    while time.time() - t0 < budget:
+        fn = (nms_case, ragged_case, yolo_case, prior_case, pre_case, nms_case)[seed % 6]
+        ok, info = fn(seed)
+        per_kind[info["kind"]] += 1
+        n += 1
+        if not ok:
+            fails.append(info)
+            print("FAIL", json.dumps(info), flush=True)
+        if n % 25 == 0:
+            print("cases %d  failures %d  %.0f s" % (n, len(fails), time.time() - t0), flush=True)
+        seed += 1
+    print(json.dumps({"cases": n, "per_kind": per_kind, "n_failures": len(fails), "failures": fails[:12], "seconds": round(time.time() - t0, 1),
+                      "first_seed": first}), flush=True)
+    sys.exit(1 if fails else 0)

@@ -53,6 +53,20 @@ def test_fuzz_batched_nms(seed):
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), (seed, thr, boxes.shape)
 
 
+@pytest.mark.parametrize("K", [17000, 33000])
+def test_highest_class_index_on_the_multi_kernel_path(K):
+    """Class 4095 (the last one a key can hold) with more candidates than the single-launch kernel sorts: its
+    segment has no successor class to search for (found by tests/fuzz_campaign.py)."""
+    g = torch.Generator().manual_seed(K)
+    boxes = _boxes("normal", K, g).contiguous()
+    scores = torch.rand(K, generator=g)
+    cls = torch.randint(4000, 4096, (K,), generator=g)
+    cls[::7] = 4095
+    ref = O.batched_nms(boxes, scores, cls, torch.tensor([0.45]))
+    got = V.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([0.45]))
+    assert torch.equal(got.cpu(), ref)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_ragged_batch_with_top_k(seed):
     """One launch, B images with different candidate counts (incl. 0 and 1) and a top_k; each image against the

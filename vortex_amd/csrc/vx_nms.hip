@@ -554,7 +554,8 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
         int lo = vx_lower_bound_wave(k1, n, (u64)c << 52);
         if (lo >= n) break;                              // no class >= c left (keys ascending)
         if (vx_key1_cls(k1[lo]) != c) continue;
-        int hi = vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52);
+        // the last class has no successor: (c + 1) << 52 would wrap to 0 for c = 4095
+        int hi = c + 1 < VX_MAX_CLASSES ? vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52) : n;
         int len = hi - lo;
         if (len <= 64 * VX_SWEEP_WT) {
             vx_sweep_wave(sb, sa, k1, lo, len, T, k2, c2);
