@@ -142,16 +142,129 @@ def pre_case(seed):
     return ok, dict(kind="pre", seed=seed, B=B, H=H, W=W, oh=oh, ow=ow, letterbox=lb, flip=flip)
 
 
+def layer_case(seed):
+    """Raw-head boundary at any S up to 640 (R > 16384 from S = 544: optimistic NMS, deferred + redo when dense):
+    fused == threshold-first == YoloV3Layer x3 + decoder, one-call pipeline with top_k == oracle NMS on them."""
+    g = torch.Generator().manual_seed(130_000 + seed)
+    S = 32 * int(torch.randint(1, 21, (1,), generator=g))
+    C = [1, 2, 5, 20, 80, 243][seed % 6]
+    B = 1 + seed % 2 if S > 416 else 1 + seed % 5
+    thr = [0.9, 0.5, 0.01, 0.97, 0.0, 0.7][(seed // 2) % 6]
+    top_k = [None, 10, 300][seed % 3]
+    heads = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=140_000 + seed)]
+    a = ops.yolo_fused_decode(heads, S, thr)
+    t = ops.yolo_fused_decode(heads, S, thr, threshold_first=True)
+    out = torch.empty((B, ops.yolo_rows(S), 5 + C), device=DEV)
+    off = 0
+    for h, mask in zip(heads, O.ANCHOR_MASKS):
+        G = h.shape[-1]
+        V.YoloV3Layer(S, (G, G), list(mask), O.COCO_ANCHORS, C).to(DEV).eval()(h, out=out, row_offset=off)
+        off += 3 * G * G
+    u = ops.yolo_decode(out, S, thr)
+    ok = torch.equal(a.meta, t.meta) and torch.equal(a.meta, u.meta)
+    it = torch.tensor([[0.2, 0.45, 0.6][seed % 3]])
+    res = V.YoloV3FusedPostProcess(S, top_k=top_k)(heads, torch.tensor([thr]), it)
+    for b, k in enumerate(a.counts.cpu().tolist()):
+        for x, y, z in ((a.boxes, t.boxes, u.boxes), (a.scores, t.scores, u.scores), (a.cls, t.cls, u.cls), (a.det, t.det, u.det)):
+            ok = ok and torch.equal(x[b, :k], y[b, :k]) and torch.equal(x[b, :k], z[b, :k])
+        if k <= 12000:                                   # O(K^2) oracle
+            keep = O.batched_nms(a.boxes[b, :k].cpu(), a.scores[b, :k].cpu(), a.cls[b, :k].cpu(), it)
+            if top_k is not None:
+                keep = keep[:top_k]
+            ok = ok and torch.equal(res[b].cpu(), a.det[b, :k].cpu()[keep])
+    return ok, dict(kind="layer", seed=seed, S=S, C=C, B=B, thr=thr, top_k=top_k)
+
+
+def format_case(seed):
+    import numpy as np
+    g = torch.Generator().manual_seed(150_000 + seed)
+    B, cap, D = 1 + seed % 7, int(torch.randint(1, 400, (1,), generator=g)), [6, 16, 7, 64][seed % 4]
+    det = torch.randn(B, cap, D, generator=g)
+    counts = torch.randint(0, cap + 1, (B,), generator=g).to(torch.int32)
+    ncol = int(torch.randint(1, 65, (1,), generator=g))
+    cols = torch.randint(0, D, (ncol,), generator=g).tolist()
+    kinds = torch.randint(0, 3, (ncol,), generator=g).tolist()
+    wh = (torch.rand(B, 2, generator=g) * 2000 + 1).float()
+    rows = ops.format_results(det.to(DEV), counts.to(DEV), cols, kinds, wh.to(DEV)).cpu()
+    exp = []
+    for b in range(B):
+        e = det[b, :int(counts[b])][:, cols].clone()
+        for j, kd in enumerate(kinds):
+            if kd:
+                e[:, j] = e[:, j] * wh[b, kd - 1]
+        exp.append(e)
+    exp = torch.cat(exp) if exp else torch.zeros(0, ncol)
+    ok = torch.equal(rows[:exp.shape[0]], exp)
+    packed = ops.pack_rows(det.to(DEV), counts.to(DEV)).cpu()
+    flat = torch.cat([det[b, :int(counts[b])] for b in range(B)])
+    ok = ok and torch.equal(packed[:flat.shape[0]], flat)
+    return ok, dict(kind="format", seed=seed, B=B, cap=cap, D=D, ncol=ncol)
+
+
+def detr_case(seed):
+    from tests.test_gpu_parity import _detr_check
+    g = torch.Generator().manual_seed(160_000 + seed)
+    B, Q = 1 + seed % 9, int(torch.randint(1, 700, (1,), generator=g))
+    NL = [2, 3, 92, 65, 1204][seed % 5]
+    thr = [0.5, 0.3, 0.0, 0.9, 0.05][(seed // 5) % 5]
+    x = O.synth_detr_outputs(B, Q, NL, 170_000 + seed)
+    try:
+        _detr_check(x, thr, O.detr_postprocess(x, torch.tensor([thr])))
+        ok = True
+    except AssertionError:
+        ok = False
+    lg = torch.randn(B * 3, NL, generator=g) * 3
+    r, e = V.SoftmaxPostProcess()(lg.to(DEV)).cpu(), O.softmax_postprocess(lg)
+    p = torch.softmax(lg, 1).topk(2, 1).values
+    clear = (p[:, 0] - p[:, 1]) > 2e-5 * p[:, 0]
+    ok = ok and torch.equal(r[clear, 0], e[clear, 0]) and torch.allclose(r[:, 1], e[:, 1], rtol=1e-5, atol=0)
+    return ok, dict(kind="detr", seed=seed, B=B, Q=Q, NL=NL, thr=thr)
+
+
+def nan_case(seed):
+    """One NaN anywhere in the input -> ValueError (postprocess/yolov3.py:35-36) on every YOLO entry; without
+    it no error."""
+    g = torch.Generator().manual_seed(180_000 + seed)
+    S, C, B = 32 * (1 + seed % 6), [1, 3, 80][seed % 3], 1 + seed % 3
+    heads = O.synth_yolo_heads(B, S, C, seed=190_000 + seed)
+    hi = int(torch.randint(0, 3, (1,), generator=g))
+    flat = heads[hi].view(-1)
+    pos = int(torch.randint(0, flat.numel(), (1,), generator=g))
+    st, it = torch.tensor([[0.9, 0.3][seed % 2]]), torch.tensor([0.45])
+    pred = O.yolo_head_eval(heads, S)
+    ok = True
+    try:
+        V.YoloV3FusedPostProcess(S)([h.to(DEV) for h in heads], st, it)
+        V.YoloV3PostProcess(S)(pred.to(DEV), st, it)
+    except ValueError:
+        ok = False
+    flat[pos] = float("nan")
+    pred2 = pred.clone()
+    pred2.view(-1)[int(torch.randint(0, pred2.numel(), (1,), generator=g))] = float("nan")
+    for fn in (lambda: V.YoloV3FusedPostProcess(S)([h.to(DEV) for h in heads], st, it),
+               lambda: V.YoloV3PostProcess(S)(pred2.to(DEV), st, it)):
+        try:
+            fn()
+            ok = False
+        except ValueError:
+            pass
+    return ok, dict(kind="nan", seed=seed, S=S, C=C, B=B, head=hi, pos=pos)
+
+
+CASES = (nms_case, ragged_case, yolo_case, prior_case, pre_case, layer_case, format_case, detr_case, nan_case,
+         nms_case, layer_case)
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0, n, fails = time.time(), 0, []
-    per_kind = {"nms": 0, "yolo": 0, "prior": 0, "ragged": 0, "pre": 0}
+    per_kind = {}
     seed = first
     while time.time() - t0 < budget:
-        fn = (nms_case, ragged_case, yolo_case, prior_case, pre_case, nms_case)[seed % 6]
+        fn = CASES[seed % len(CASES)]
         ok, info = fn(seed)
-        per_kind[info["kind"]] += 1
+        per_kind[info["kind"]] = per_kind.get(info["kind"], 0) + 1
         n += 1
         if not ok:
             fails.append(info)
