@@ -83,9 +83,28 @@ def prior_case(seed):
     c = pp.decoder.decode_batch(x.to(DEV), st) if hasattr(pp.decoder, "decode_batch") else None
     ok = len(got) == B
     if c is not None:
+        from tests.test_gpu_parity import close, same
         for b, k in enumerate(c.counts.cpu().tolist()):
             keep = O.batched_nms(c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu(), it)
             ok = ok and torch.equal(got[b].cpu(), c.det[b, :k].cpu()[keep])
+            # decode itself against the oracle (tolerance class: exp / softmax, 1e-5 rel)
+            bb, sc, ci, det = O.prior_box_decode(x[b:b + 1], priors, st, Lm)
+            if k != bb.shape[0]:                         # a confidence within the tolerance of the threshold
+                n_hi = O.prior_box_decode(x[b:b + 1], priors, st * (1 - 3e-5), Lm)[0].shape[0]
+                n_lo = O.prior_box_decode(x[b:b + 1], priors, st * (1 + 3e-5), Lm)[0].shape[0]
+                ok = ok and n_lo <= k <= n_hi
+                continue
+            try:
+                close(c.boxes[b, :k], bb); close(c.scores[b, :k], sc)
+                cols = [0, 1, 2, 3, 4] + list(range(6, 6 + 2 * Lm))
+                close(c.det[b, :k][:, cols], det[0][:, cols])
+                amb = torch.softmax(x[b, :, 4 + 2 * Lm:], 1)[:, 1:].topk(min(2, NL - 1), 1).values
+                if NL > 2 and bool(((amb[:, 0] - amb[:, 1]) <= 2e-5 * amb[:, 0]).any()):
+                    pass                                 # two classes within the tolerance: label may differ
+                else:
+                    same(c.cls[b, :k], ci)
+            except AssertionError:
+                ok = False
     return ok, dict(kind="prior", seed=seed, P=P, L=Lm, NL=NL, B=B, sthr=sthr)
 
 
