@@ -67,6 +67,30 @@ def test_highest_class_index_on_the_multi_kernel_path(K):
     assert torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize("cap", [40, 700, 17000])
+def test_counts_outside_the_capacity_are_clamped(cap):
+    """A caller-supplied count below 0 reads as 0, above the capacity as the capacity (no out-of-range access),
+    on the single-wave, single-launch and multi-kernel paths, and in the packing / formatting kernels."""
+    g = torch.Generator().manual_seed(cap)
+    B, C = 3, 5
+    boxes = torch.stack([_boxes("normal", cap, g) for _ in range(B)]).contiguous()
+    scores = torch.rand(B, cap, generator=g)
+    cls = torch.randint(0, C, (B, cap), generator=g)
+    det = torch.randn(B, cap, 6, generator=g)
+    counts = torch.tensor([-3, cap + 100, min(5, cap)], dtype=torch.int32)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(DEV), 0.5, C, None)
+    assert int(status.item()) == 0
+    kc = keep_counts.cpu().tolist()
+    for b, n in enumerate([0, cap, min(5, cap)]):
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([0.5]))
+        assert kc[b] == ref.numel() and torch.equal(keep_idx[b, :kc[b]].cpu(), ref)
+    packed = ops.pack_rows(det.to(DEV), counts.to(DEV)).cpu()
+    assert torch.equal(packed[:cap + min(5, cap)], torch.cat((det[1], det[2, :min(5, cap)])))
+    rows = ops.format_results(det.to(DEV), counts.to(DEV), [0, 5]).cpu()
+    assert torch.equal(rows[:cap + min(5, cap)], torch.cat((det[1], det[2, :min(5, cap)]))[:, [0, 5]])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_ragged_batch_with_top_k(seed):
     """One launch, B images with different candidate counts (incl. 0 and 1) and a top_k; each image against the

@@ -88,3 +88,6 @@ __host__ __device__ __forceinline__ int vx_next_pow2(int n) {
     while (p < n) p <<= 1;
     return p;
 }
+
+// per-image row count as read from a caller-supplied device array: [0, cap] whatever the array holds
+__device__ __forceinline__ int vx_clamp_count(int c, int cap) { return c < 0 ? 0 : (c > cap ? cap : c); }

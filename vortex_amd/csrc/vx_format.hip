@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void vx_k_format_results(const float *__restri
     __shared__ int s_part[256];
     const int b = blockIdx.x;
     int acc = 0;
-    for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
+    for (int i = threadIdx.x; i < b; i += 256) acc += vx_clamp_count(counts[i], cap);
     s_part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void vx_k_format_results(const float *__restri
         __syncthreads();
     }
     const long long off = s_part[0];
-    const int n = min(counts[b], cap);
+    const int n = vx_clamp_count(counts[b], cap);
     if (b == B - 1 && threadIdx.x == 0 && total) *total = (int)off + n;
     const float w = img_wh ? img_wh[2 * b] : 1.0f, h = img_wh ? img_wh[2 * b + 1] : 1.0f;
     const float *s = src + (long long)b * cap * D;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restri
                                                            u64 *__restrict__ keys1, int *__restrict__ count2,
                                                            int *__restrict__ status) {
     int b = blockIdx.y;
-    int n = counts ? min(counts[b], p.cap) : p.cap;
+    int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
     int k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0) count2[b] = 0;
     if (k < n) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     const int b = blockIdx.y;
     if (ep.sel && ep.sel[b] == 0) return;
-    const int n = counts ? min(counts[b], sp.stride) : sp.fixed_n;
+    const int n = counts ? vx_clamp_count(counts[b], sp.stride) : sp.fixed_n;
     const int npad = vx_next_pow2(max(n, 1));
     const int base = blockIdx.x * sp.CH;
     if (base >= npad) return;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
 __global__ __launch_bounds__(256) void vx_k_sort_global(u64 *__restrict__ keys, const int *__restrict__ counts,
                                                         int stride, int fixed_n, int k, int j) {
     const int b = blockIdx.y;
-    const int n = counts ? min(counts[b], stride) : fixed_n;
+    const int n = counts ? vx_clamp_count(counts[b], stride) : fixed_n;
     const int npad = vx_next_pow2(max(n, 1));
     if (k > npad) return;
     int t = blockIdx.x * 256 + threadIdx.x;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
     __shared__ int s_big[VX_SWEEP_MAXBIG][2];
     __shared__ int s_nbig;
     const int b = blockIdx.y;
-    const int n = counts ? min(counts[b], p.cap) : p.cap;
+    const int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
     if (n == 0) return;
     const long long ob = (long long)b * p.npad_cap;
     const u64 *k1 = keys1 + ob;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
     const vx_nms_params &p = a.p;
     const int b = blockIdx.x, nt = blockDim.x;
-    const int n = a.counts ? min(a.counts[b], p.cap) : p.cap;
+    const int n = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
     if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
         const bool big = n > a.n_max;
         if (threadIdx.x == 0) {
@@ -988,14 +988,14 @@ __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ 
     __shared__ int s_part[256];
     // workgroup (g, b) copies rows [g*VX_PACK_ROWS, (g+1)*VX_PACK_ROWS) of image b; most leave at once
     const int b = blockIdx.y, g = blockIdx.x;
-    const int n = min(counts[b], cap);
+    const int n = vx_clamp_count(counts[b], cap);
     if (g > 0 && g * VX_PACK_ROWS >= n) return;
     // the counts / status words of the call chain, mirrored for the host (meta_dst may be pinned host memory:
     // plain stores, visible after the stream's next event) so the path needs no D2H memcpy
     if (b == 0 && g == 0 && meta_dst)
         for (int i = threadIdx.x; i < n_meta; i += 256) meta_dst[i] = meta_src[i];
     int acc = 0;
-    for (int i = threadIdx.x; i < b; i += 256) acc += min(counts[i], cap);
+    for (int i = threadIdx.x; i < b; i += 256) acc += vx_clamp_count(counts[i], cap);
     s_part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
