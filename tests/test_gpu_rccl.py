@@ -1,0 +1,60 @@
+"""The all-gather of detections over RCCL (torch.distributed backend "nccl") on the one GPU of the test box:
+a world of one rank exercises the same calls the N-GPU run makes (all_gather_into_tensor of the counts and of
+the padded rows, device tensors in, device tensors out).  The world-size-2 logic is covered on CPU by
+tests/test_parallel_gloo.py.  Runs in a child process so that a stuck rendezvous cannot hang the suite."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    import torch.distributed as dist
+    import vortex_amd as V
+    from vortex_amd import parallel
+    from oracle import vortex_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        S, C, B = 64, 80, 4
+        heads = [h.to(dev) for h in O.synth_yolo_heads(B, S, C, seed=7)]
+        st, it = torch.tensor([0.06]), torch.tensor([0.2])
+        post = V.YoloV3FusedPostProcess(S)
+        ref = post(heads, st, it)
+        packed, meta = post.forward_device(heads, st, it)
+        got = parallel.allgather_detections(packed, meta, B)
+        ok = len(got) == B and all(a.is_cuda and torch.equal(a, b) for a, b in zip(got, ref))
+        shard = parallel.shard_batch(heads[0])
+        ok = ok and shard.shape == heads[0].shape
+        dist.barrier()
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_detections_over_rccl_world1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        assert q.get(timeout=150) is True
+    finally:
+        p.join(30)
+        if p.is_alive():
+            p.kill()

@@ -794,10 +794,8 @@ static int vx_fused_tiles(int S) {
     const int div[3] = {32, 16, 8};
     for (int i = 0; i < 3; ++i) {
         int G = S / div[i], cells = G * G;
-        int tc = (cells % 4 == 0) ? 256 : 64;
-        // a misaligned head pointer falls back to 64-cell tiles: size for the finer tiling
+        // sized for 64-cell tiles (>= the 256-cell tiling the kernels use): one size for every tiling
         tiles += 3 * ((cells + 63) / 64);
-        (void)tc;
     }
     return tiles;
 }
