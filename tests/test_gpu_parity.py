@@ -456,6 +456,17 @@ def test_softmax_postprocess_shapes_and_errors():
         V.SoftmaxPostProcess()(torch.randn(5, 7, 2).to(DEV))
 
 
+def test_zero_image_batches_return_empty_tuples():
+    """The reference loops over the images (base_postprocess.py:131-138, detr.py:544-548): no image, empty tuple."""
+    st, it = torch.tensor([0.5]), torch.tensor([0.5])
+    assert V.YoloV3PostProcess(64)(torch.zeros(0, 252, 85, device=DEV), st, it) == ()
+    heads = [torch.zeros(0, 255, g, g, device=DEV) for g in (2, 4, 8)]
+    assert V.YoloV3FusedPostProcess(64)(heads, st, it) == ()
+    assert V.DETRPostProcess()(torch.zeros(0, 100, 96, device=DEV), score_threshold=st) == ()
+    pri = torch.rand(30, 4, device=DEV)
+    assert V.PriorBoxPostProcess(pri, n_landmarks=0).to(DEV)(torch.zeros(0, 30, 6, device=DEV), st, it) == ()
+
+
 # ------------------------------------------------------------------------------------------- callers
 def test_predictor_end_to_end_and_results():
     """BasePredictor(preprocess -> model -> postprocess) with a stand-in model that returns a decoded head,

@@ -36,4 +36,6 @@ class DETRPostProcess(nn.Module):
 
     @torch.no_grad()
     def forward(self, inputs: torch.Tensor, score_threshold: torch.Tensor, **kwargs) -> torch.Tensor:
+        if inputs.ndim == 3 and inputs.size(0) == 0:
+            return tuple()                               # the reference's loop over zero images (detr.py:545-548)
         return self.forward_async(inputs, score_threshold).result()

@@ -11,6 +11,7 @@ single D2H copy (the reference loops per image in Python).
 Build-side extensions (default off == reference behaviour): `top_k`, and YoloV3FusedPostProcess which
 takes the three raw head tensors and never materialises the decoded [B,R,5+C] tensor."""
 import collections
+import threading
 from typing import Callable, Optional, Sequence, Tuple, Union
 
 import torch
@@ -204,6 +205,9 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         return pend
 
     def forward(self, input: torch.Tensor, score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
+        first = input[0] if isinstance(input, (list, tuple)) else input
+        if first.size(0) == 0:
+            return tuple()                               # the reference's loop over zero images
         if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
             return self.forward_async(input, score_threshold, iou_threshold).result()
         n_batch = input.size(0)
@@ -227,6 +231,7 @@ def finish_results(packed: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tens
 
 
 _INFLIGHT = collections.deque()       # (event, pinned mirror, packed, meta) of calls whose GPU work may be pending
+_INFLIGHT_LOCK = threading.Lock()     # serving threads share the deque
 
 
 class PendingDetections:
@@ -243,9 +248,10 @@ class PendingDetections:
         self._event.record(torch.cuda.current_stream(meta.device))
         # A KERNEL writes the pinned mirror, which torch's host allocator cannot know: keep the buffer (and the
         # device tensors) referenced until the event has fired even if the caller drops this object early.
-        _INFLIGHT.append((self._event, host, packed, meta))
-        while _INFLIGHT and _INFLIGHT[0][0].query():
-            _INFLIGHT.popleft()
+        with _INFLIGHT_LOCK:
+            _INFLIGHT.append((self._event, host, packed, meta))
+            while _INFLIGHT and _INFLIGHT[0][0].query():
+                _INFLIGHT.popleft()
 
     @classmethod
     def packing(cls, out_det: torch.Tensor, keep_counts: torch.Tensor, meta: torch.Tensor) -> "PendingDetections":
@@ -319,6 +325,8 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
         return pend
 
     def forward(self, input: Sequence[torch.Tensor], score_threshold: torch.Tensor, iou_threshold: torch.Tensor):
+        if input[0].size(0) == 0:
+            return tuple()
         return self.forward_async(input, score_threshold, iou_threshold).result()
 
 
