@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void vx_k_sort_global(u64 *__restrict__ keys, 
 // instructions) is only executed when the cheap bracket  inter > fl(thr(1+2^-19))*uni  /
 // inter < fl(thr(1-2^-19))*uni  cannot decide: inside the bracket the true quotient is more than
 // 2^-20 relative (>= 4 ulp) away from thr, so the rounded quotient falls on the same side — the
-// result is bit-identical, the undecided band is hit by ~1 pair in 10^5.  max/min use v_max/v_min:
+// result is bit-identical, the undecided band is hit by ~1 pair in 10^5.  max/min are v_max_f32/v_min_f32:
 // they differ from std::max/min only for NaN or signed-zero operands, which cannot change w, h.
 struct vx_thr { float thr, hi, lo; bool fast; };
 
@@ -260,15 +260,32 @@ __device__ __forceinline__ vx_thr vx_make_thr(float thr) {
     return t;
 }
 
+// v_max_f32 / v_min_f32 as written: the compiler's fmaxf/fminf (and fmed3 with an infinite operand, which it
+// folds to them) canonicalise both inputs first (v_max_f32 x, x, x) because they came from memory -- 8 extra
+// instructions per IoU in the sweep's inner loop.  IU: the first operand is wave-uniform (a readlane result) and
+// stays in a scalar register.
+template <bool IU> __device__ __forceinline__ float vx_vmax(float a, float b) {
+    float r;
+    if (IU) asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    else    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool IU> __device__ __forceinline__ float vx_vmin(float a, float b) {
+    float r;
+    if (IU) asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    else    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <bool IU>
 __device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
                                           float jx1, float jy1, float jx2, float jy2, float ja, const vx_thr &T) {
-    // v_med3_f32(a, b, +-inf) = max / min in one instruction, no canonicalising pre-ops
-    float xx1 = __builtin_amdgcn_fmed3f(ix1, jx1, INFINITY);
-    float yy1 = __builtin_amdgcn_fmed3f(iy1, jy1, INFINITY);
-    float xx2 = __builtin_amdgcn_fmed3f(ix2, jx2, -INFINITY);
-    float yy2 = __builtin_amdgcn_fmed3f(iy2, jy2, -INFINITY);
-    float w = __builtin_amdgcn_fmed3f(xx2 - xx1, 0.0f, INFINITY);
-    float h = __builtin_amdgcn_fmed3f(yy2 - yy1, 0.0f, INFINITY);
+    float xx1 = vx_vmax<IU>(ix1, jx1);
+    float yy1 = vx_vmax<IU>(iy1, jy1);
+    float xx2 = vx_vmin<IU>(ix2, jx2);
+    float yy2 = vx_vmin<IU>(iy2, jy2);
+    float w = vx_vmax<false>(xx2 - xx1, 0.0f);
+    float h = vx_vmax<false>(yy2 - yy1, 0.0f);
     float inter = w * h;
     float uni = ia + ja - inter;
     if (T.fast) {
@@ -355,7 +372,7 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
             float ia = __shfl(ar, i);
             float jx1 = __shfl(bx.x, j), jy1 = __shfl(bx.y, j), jx2 = __shfl(bx.z, j), jy2 = __shfl(bx.w, j);
             float ja = __shfl(ar, j);
-            bool sup = pv && vx_iou_gt(ix1, iy1, ix2, iy2, ia, jx1, jy1, jx2, jy2, ja, thr);
+            bool sup = pv && vx_iou_gt<false>(ix1, iy1, ix2, iy2, ia, jx1, jy1, jx2, jy2, ja, thr);
             if (sup) atomicOr((unsigned long long *)&wmask[i], 1ull << j);
         }
         __builtin_amdgcn_wave_barrier();
@@ -402,7 +419,7 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
 #pragma unroll
                 for (int u = t; u < VX_SWEEP_WT; ++u) {
                     if (u * 64 < n) {
-                        bool sup = vx_iou_gt(bx1, by1, bx2, by2, ba, x1[u], y1[u], x2[u], y2[u], ar[u], thr);
+                        bool sup = vx_iou_gt<true>(bx1, by1, bx2, by2, ba, x1[u], y1[u], x2[u], y2[u], ar[u], thr);
                         if (u == t) sup = sup && (lane > i);
                         alive[u] = alive[u] && !sup;
                     }
@@ -442,10 +459,19 @@ typedef vx_sweep_smem_t<VX_SORT_CHMAX / 64> vx_sweep_smem_image;      // single-
 template <class SM>
 __device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, const vx_f4 &bx, float a,
                                               bool al, const vx_thr &thr) {
-    for (int q = 0; q < kc; ++q) {
+    // two kept boxes per trip: both LDS reads are in flight before the first IoU chain starts
+    int q = 0;
+    for (; q + 1 < kc; q += 2) {
+        vx_f4 k0 = S.kbox[buf][q], k1 = S.kbox[buf][q + 1];
+        float a0 = S.karea[buf][q], a1 = S.karea[buf][q + 1];
+        bool s0 = vx_iou_gt<false>(k0.x, k0.y, k0.z, k0.w, a0, bx.x, bx.y, bx.z, bx.w, a, thr);
+        bool s1 = vx_iou_gt<false>(k1.x, k1.y, k1.z, k1.w, a1, bx.x, bx.y, bx.z, bx.w, a, thr);
+        if (s0 || s1) al = false;
+    }
+    if (q < kc) {
         vx_f4 kb = S.kbox[buf][q];
         float ka = S.karea[buf][q];
-        if (vx_iou_gt(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
+        if (vx_iou_gt<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
     }
     return al;
 }
@@ -471,7 +497,7 @@ __device__ __forceinline__ void vx_resolve_tile(SM &S, const vx_f4 *__restrict__
         int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
         float bx1 = vx_bcast(bx.x, i), by1 = vx_bcast(bx.y, i);
         float bx2 = vx_bcast(bx.z, i), by2 = vx_bcast(bx.w, i), ba = vx_bcast(a, i);
-        bool sup = (lane > i) && vx_iou_gt(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
+        bool sup = (lane > i) && vx_iou_gt<true>(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
         al &= ~__ballot(sup);
         todo = al & ~((2ull << i) - 1ull);
     }
@@ -648,7 +674,7 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
         const float ix1 = vx_bcast(bx.x, i), iy1 = vx_bcast(bx.y, i), ix2 = vx_bcast(bx.z, i), iy2 = vx_bcast(bx.w, i);
         const float ia = vx_bcast(ar, i);
         const int ci = __builtin_amdgcn_readlane(cl, i);
-        bool sup = valid && lane > i && cl == ci && vx_iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, T);
+        bool sup = valid && lane > i && cl == ci && vx_iou_gt<true>(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, T);
         alive &= ~__ballot(sup);
         todo = alive & ~((2ull << i) - 1ull);
     }
