@@ -278,20 +278,35 @@ template <bool IU> __device__ __forceinline__ float vx_vmin(float a, float b) {
 }
 
 template <bool IU>
-__device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
-                                          float jx1, float jy1, float jx2, float jy2, float ja, const vx_thr &T) {
+__device__ __forceinline__ void vx_iou_parts(float ix1, float iy1, float ix2, float iy2, float ia,
+                                             float jx1, float jy1, float jx2, float jy2, float ja,
+                                             float &inter, float &uni) {
     float xx1 = vx_vmax<IU>(ix1, jx1);
     float yy1 = vx_vmax<IU>(iy1, jy1);
     float xx2 = vx_vmin<IU>(ix2, jx2);
     float yy2 = vx_vmin<IU>(iy2, jy2);
     float w = vx_vmax<false>(xx2 - xx1, 0.0f);
     float h = vx_vmax<false>(yy2 - yy1, 0.0f);
-    float inter = w * h;
-    float uni = ia + ja - inter;
+    inter = w * h;
+    uni = ia + ja - inter;
+}
+
+// bracket test only (T.fast): returns the decision where the bracket decides, sets `und` where it does not
+__device__ __forceinline__ bool vx_iou_bracket(float inter, float uni, const vx_thr &T, bool &und) {
+    bool hi = inter > T.hi * uni, lo = inter < T.lo * uni;
+    und = und || !((hi || lo) && uni > 1e-30f && uni < 1e30f);
+    return hi;
+}
+
+template <bool IU>
+__device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
+                                          float jx1, float jy1, float jx2, float jy2, float ja, const vx_thr &T) {
+    float inter, uni;
+    vx_iou_parts<IU>(ix1, iy1, ix2, iy2, ia, jx1, jy1, jx2, jy2, ja, inter, uni);
     if (T.fast) {
-        bool hi = inter > T.hi * uni, lo = inter < T.lo * uni;
-        bool res = hi;
-        if (!((hi || lo) && uni > 1e-30f && uni < 1e30f)) res = (inter / uni) > T.thr;
+        bool und = false;
+        bool res = vx_iou_bracket(inter, uni, T, und);
+        if (und) res = (inter / uni) > T.thr;
         return res;
     }
     return (inter / uni) > T.thr;
@@ -459,21 +474,39 @@ typedef vx_sweep_smem_t<VX_SORT_CHMAX / 64> vx_sweep_smem_image;      // single-
 template <class SM>
 __device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, const vx_f4 &bx, float a,
                                               bool al, const vx_thr &thr) {
-    // two kept boxes per trip: both LDS reads are in flight before the first IoU chain starts
-    int q = 0;
-    for (; q + 1 < kc; q += 2) {
-        vx_f4 k0 = S.kbox[buf][q], k1 = S.kbox[buf][q + 1];
-        float a0 = S.karea[buf][q], a1 = S.karea[buf][q + 1];
-        bool s0 = vx_iou_gt<false>(k0.x, k0.y, k0.z, k0.w, a0, bx.x, bx.y, bx.z, bx.w, a, thr);
-        bool s1 = vx_iou_gt<false>(k1.x, k1.y, k1.z, k1.w, a1, bx.x, bx.y, bx.z, bx.w, a, thr);
-        if (s0 || s1) al = false;
+    bool sup = false, und = !thr.fast;
+    if (thr.fast) {
+        // bracket tests only, no branch inside the loop; two kept boxes per trip (independent chains, both LDS
+        // reads in flight).  A lane that meets a pair the bracket cannot decide (~1 in 10^5) repeats its loop
+        // with the division below.
+        int q = 0;
+        for (; q + 1 < kc; q += 2) {
+            vx_f4 k0 = S.kbox[buf][q], k1 = S.kbox[buf][q + 1];
+            float a0 = S.karea[buf][q], a1 = S.karea[buf][q + 1];
+            float i0, u0, i1, u1;
+            vx_iou_parts<false>(k0.x, k0.y, k0.z, k0.w, a0, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
+            vx_iou_parts<false>(k1.x, k1.y, k1.z, k1.w, a1, bx.x, bx.y, bx.z, bx.w, a, i1, u1);
+            bool s0 = vx_iou_bracket(i0, u0, thr, und);
+            bool s1 = vx_iou_bracket(i1, u1, thr, und);
+            sup = sup || s0 || s1;
+        }
+        if (q < kc) {
+            vx_f4 kb = S.kbox[buf][q];
+            float ka = S.karea[buf][q], i0, u0;
+            vx_iou_parts<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
+            sup = vx_iou_bracket(i0, u0, thr, und) || sup;
+        }
     }
-    if (q < kc) {
-        vx_f4 kb = S.kbox[buf][q];
-        float ka = S.karea[buf][q];
-        if (vx_iou_gt<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, thr)) al = false;
+    if (und) {
+        sup = false;
+        for (int q = 0; q < kc; ++q) {
+            vx_f4 kb = S.kbox[buf][q];
+            float ka = S.karea[buf][q], i0, u0;
+            vx_iou_parts<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
+            sup = sup || (i0 / u0) > thr.thr;
+        }
     }
-    return al;
+    return al && !sup;
 }
 
 // wave 0: tile t (already hit by every earlier kept box except those in `prev_buf`, if any) ->
