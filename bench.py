@@ -154,29 +154,11 @@ def main():
 
     two_streams = args.streams > 1 and not args.unfused and not args.allgather
     if two_streams:
-        s_post = torch.cuda.Stream(dev, priority=-1)        # decode + NMS tail (short kernels: high priority)
-        s_pre = torch.cuda.Stream(dev)                      # normalize
-        s_post.wait_stream(torch.cuda.current_stream(dev))
-
-    def step_two_streams():
-        """Same launches as step(); K1 goes to s_pre between this step's decode and the next step's decode, so
-        the two streaming kernels never share HBM (clean per-kernel timing) and the NMS tail hides behind K1."""
-        with torch.cuda.stream(s_post):
-            c = post.decoder.decode_batch(heads, sthr)                      # fused decode + cand_finish
-            decoded = s_post.record_event()
-        with torch.cuda.stream(s_pre):
-            s_pre.wait_event(decoded)
-            x = norm(img)                                                   # K1 (consumed by the backbone)
-            pre_done = s_pre.record_event()
-        with torch.cuda.stream(s_post):
-            _, out_det, keep_counts, _ = ops.candidates_nms(c, args.iou_thr, C, None)
-            pend = V.postprocess.PendingDetections.packing(out_det, keep_counts, c.meta)
-            s_post.wait_event(pre_done)                                     # next decode starts after K1
-        return x, pend if args.depth > 1 else pend.result()
+        # NMS + packing of a batch on a second stream behind the decode (vx_yolo_fused_postprocess_overlapped): the
+        # current stream carries only K1 and the fused decode, back to back
+        post.tail_stream = torch.cuda.Stream(dev, priority=-1)
 
     def step():
-        if two_streams:
-            return step_two_streams()
         x = norm(img)                                       # K1 (consumed by the backbone, out of scope)
         inp = heads
         if args.unfused:

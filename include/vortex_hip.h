@@ -215,7 +215,7 @@ int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacit
  * base_postprocess.py:110-138) from the three raw head tensors.
  *   d_packed f32[B*out_cap*6]: kept rows (x1,y1,x2,y2,class_conf,class) of image 0, then image 1, ...
  *                              out_cap = min(top_k, R) when top_k > 0, else R = 3*sum(G_s^2)
- *   d_meta   i32[2B+1]       : counts[B] | keep_counts[B] | status  (zeroed here; status bits as above)
+ *   d_meta   i32[2B+1]       : counts[B] | keep_counts[B] | status  (every word written here; status bits as above)
  *   meta_mirror (optional)   : the same 2B+1 words copied to this device-accessible address (pinned host memory)
  * use_threshold takes the VX_DECODE_* bits and VX_POSTPROCESS_NMS_OPTIMISTIC.  The workspace holds every
  * intermediate. */
@@ -225,6 +225,17 @@ int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const 
                               float score_threshold, int use_threshold, float iou_threshold, int top_k,
                               float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
                               void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The same call with the latency-bound tail (NMS, packing, the mirror) on `tail_stream`, ordered behind the decode by
+ * an event the library records on `stream` (one hipEvent per device, created on first use): `stream` then carries
+ * only the HBM-bound decode, so the caller's next kernel on it (the next batch's pre-process) overlaps this batch's
+ * tail.  Outputs are complete once `tail_stream` has drained; the caller keeps d_packed / d_meta / d_workspace alive
+ * until then.  No reference counterpart (the reference is synchronous Python); same results as the call above. */
+int vx_yolo_fused_postprocess_overlapped(const float *d_head0, const float *d_head1, const float *d_head2,
+                                         int B, int S, int C, const float anchors_px[18],
+                                         float score_threshold, int use_threshold, float iou_threshold, int top_k,
+                                         float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
+                                         void *d_workspace, size_t workspace_bytes, void *stream, void *tail_stream);
 
 /* ---------------------------------------------------------------- result formatting
  * vx_pack_rows + the output_format column slicing of get_prediction_results (predictor/utils.py:11-33) /

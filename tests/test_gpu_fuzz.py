@@ -186,3 +186,24 @@ def test_optimistic_nms_small_and_deferred_608():
         for b, k in enumerate(c.counts.cpu().tolist()):
             keep = O.batched_nms(c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu(), it)
             assert torch.equal(res[b].cpu(), c.det[b, :k].cpu()[keep])
+
+
+def test_tail_stream_pipeline_equals_single_stream():
+    """vx_yolo_fused_postprocess_overlapped (NMS + packing on a second stream behind the decode) returns the same
+    tuples as the single-stream call, batch after batch with results collected one batch late."""
+    S, C, B = 416, 80, 4
+    tail = torch.cuda.Stream(DEV)
+    one, two = V.YoloV3FusedPostProcess(S), V.YoloV3FusedPostProcess(S, tail_stream=tail)
+    it = torch.tensor([0.45])
+    prev = None
+    for step, sthr in enumerate((0.9, 0.3, 0.06, 0.9, 0.5)):
+        heads = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=40 + step)]
+        st = torch.tensor([sthr])
+        ref = one(heads, st, it)
+        pend = two.forward_async(heads, st, it)
+        if prev is not None:
+            got, exp = prev[0].result(), prev[1]
+            assert len(got) == len(exp) and all(torch.equal(a, b) for a, b in zip(got, exp))
+        prev = (pend, ref)
+    got, exp = prev[0].result(), prev[1]
+    assert all(torch.equal(a, b) for a, b in zip(got, exp))

@@ -44,6 +44,9 @@ _SIGNATURES = {
     "vx_yolo_fused_postprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vx_yolo_fused_postprocess": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_float, c_int,
                                           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_yolo_fused_postprocess_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_float,
+                                                     c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_size_t, c_void_p, c_void_p]),
     "vx_prior_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vx_prior_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                 c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -55,10 +55,21 @@ extern "C" size_t vx_yolo_fused_postprocess_workspace_bytes(int B, int S, int to
     return vx_pipe_carve(nullptr, B, S, out_cap).total;
 }
 
-extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
-                                         int C, const float anchors_px[18], float score_threshold, int use_threshold,
-                                         float iou_threshold, int top_k, float *d_packed, int32_t *d_meta,
-                                         int32_t *meta_mirror, void *d_workspace, size_t workspace_bytes, void *stream) {
+// One event per device orders the tail stream behind the decode (vx_yolo_fused_postprocess_overlapped); created on
+// first use, kept until the process ends.  Re-recording it while an earlier wait is still queued is well defined:
+// a wait refers to the record that preceded it.
+static hipEvent_t vx_decoded_event() {
+    static hipEvent_t ev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    return ev[dev];
+}
+
+static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                        int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                        float iou_threshold, int top_k, float *d_packed, int32_t *d_meta,
+                        int32_t *meta_mirror, void *d_workspace, size_t workspace_bytes, void *stream, void *tail_stream) {
     if (!d_packed || !d_meta || !d_workspace) return VX_ERR_INVALID_ARG;
     if (B <= 0 || S < 32 || C <= 0) return VX_ERR_INVALID_ARG;
     if (((uintptr_t)d_workspace & 255) || ((uintptr_t)d_packed & 3) || ((uintptr_t)d_meta & 3)) return VX_ERR_ALIGNMENT;
@@ -75,6 +86,12 @@ extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_he
     int rc = vx_yolo_fused_decode(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, w.boxes,
                                   w.scores, w.cls, w.det, counts, status, w.fused, w.fused_bytes, stream);
     if (rc != VX_OK) return rc;
+    if (tail_stream != stream) {                       // NMS + packing on their own stream, behind the decode
+        hipEvent_t ev = vx_decoded_event();
+        if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)tail_stream, ev, 0) != hipSuccess)
+            return VX_ERR_LAUNCH;
+        stream = tail_stream;
+    }
     rc = (use_threshold & VX_POSTPROCESS_NMS_OPTIMISTIC)
              ? vx_batched_nms_small(w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k, w.keep_idx,
                                     w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream)
@@ -82,4 +99,25 @@ extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_he
                               w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream);
     if (rc != VX_OK) return rc;
     return vx_pack_rows(w.out_det, keep_counts, B, out_cap, 6, d_packed, nullptr, d_meta, meta_mirror, 2 * B + 1, stream);
+}
+
+extern "C" int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                                         int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                                         float iou_threshold, int top_k, float *d_packed, int32_t *d_meta,
+                                         int32_t *meta_mirror, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return vx_pipe_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, iou_threshold,
+                        top_k, d_packed, d_meta, meta_mirror, d_workspace, workspace_bytes, stream, stream);
+}
+
+// Same call with the latency-bound tail (NMS, packing, the mirror of the counts) on `tail_stream`, ordered behind the
+// decode by an event: the caller's `stream` holds only the HBM-bound decode, so its next kernel (the next batch's
+// pre-process) starts while this batch's tail runs.  The outputs are complete when `tail_stream` has drained.
+extern "C" int vx_yolo_fused_postprocess_overlapped(const float *d_head0, const float *d_head1, const float *d_head2,
+                                                    int B, int S, int C, const float anchors_px[18],
+                                                    float score_threshold, int use_threshold, float iou_threshold,
+                                                    int top_k, float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
+                                                    void *d_workspace, size_t workspace_bytes, void *stream,
+                                                    void *tail_stream) {
+    return vx_pipe_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, iou_threshold,
+                        top_k, d_packed, d_meta, meta_mirror, d_workspace, workspace_bytes, stream, tail_stream);
 }

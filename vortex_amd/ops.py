@@ -180,10 +180,12 @@ _ANCHOR_CACHE = {}
 
 def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float, iou_threshold: float,
                            use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False,
-                           top_k: Optional[int] = None, optimistic_nms: bool = False):
+                           top_k: Optional[int] = None, optimistic_nms: bool = False,
+                           tail_stream: Optional["torch.cuda.Stream"] = None):
     """Raw heads -> (packed f32[B*out_cap, 6], meta i32[2B+1] on the device, pinned host mirror of meta) with ONE
     library call (vx_yolo_fused_postprocess): decode, NMS and packing are chained on the current stream; wait
-    for an event recorded after this call before reading the mirror."""
+    for an event recorded after this call before reading the mirror.  tail_stream: NMS + packing run there
+    (vx_yolo_fused_postprocess_overlapped); record the event on THAT stream."""
     assert len(heads) == 3
     hs = []
     for h, d in zip(heads, (32, 16, 8)):
@@ -206,11 +208,20 @@ def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_t
     packed = torch.empty((B * out_cap, 6), dtype=torch.float32, device=dev)
     meta = torch.empty((2 * B + 1,), dtype=torch.int32, device=dev)
     host = torch.empty((2 * B + 1,), dtype=torch.int32, pin_memory=True)
-    rc = lib.vx_yolo_fused_postprocess(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C, f18,
-                                       float(score_threshold),
-                                       int(bool(use_threshold)) | (2 if threshold_first else 0) | (4 if optimistic_nms else 0),
-                                       float(iou_threshold), tk, packed.data_ptr(), meta.data_ptr(), host.data_ptr(),
-                                       ws.data_ptr(), nb, L.stream_ptr(dev))
+    flags = int(bool(use_threshold)) | (2 if threshold_first else 0) | (4 if optimistic_nms else 0)
+    if tail_stream is None:
+        rc = lib.vx_yolo_fused_postprocess(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C,
+                                           f18, float(score_threshold), flags, float(iou_threshold), tk,
+                                           packed.data_ptr(), meta.data_ptr(), host.data_ptr(), ws.data_ptr(), nb,
+                                           L.stream_ptr(dev))
+    else:
+        for t in (packed, meta, ws):
+            t.record_stream(tail_stream)           # allocated for the current stream, last used on the tail stream
+        rc = lib.vx_yolo_fused_postprocess_overlapped(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B,
+                                                      int(img_size), C, f18, float(score_threshold), flags,
+                                                      float(iou_threshold), tk, packed.data_ptr(), meta.data_ptr(),
+                                                      host.data_ptr(), ws.data_ptr(), nb, L.stream_ptr(dev),
+                                                      tail_stream.cuda_stream)
     L.check(rc, "vx_yolo_fused_postprocess")
     return packed, meta, host
 

@@ -238,14 +238,15 @@ class PendingDetections:
     """Result of forward_async: the counts travel to pinned host memory on the launch stream, an
     event marks their arrival; result() waits for that event only (not for later launches)."""
 
-    def __init__(self, packed: torch.Tensor, meta: torch.Tensor, host: Optional[torch.Tensor] = None):
+    def __init__(self, packed: torch.Tensor, meta: torch.Tensor, host: Optional[torch.Tensor] = None,
+                 stream: Optional["torch.cuda.Stream"] = None):
         self.packed = packed
         if host is None:
             host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
             host.copy_(meta, non_blocking=True)
         self._host = host
         self._event = torch.cuda.Event()
-        self._event.record(torch.cuda.current_stream(meta.device))
+        self._event.record(stream if stream is not None else torch.cuda.current_stream(meta.device))
         # A KERNEL writes the pinned mirror, which torch's host allocator cannot know: keep the buffer (and the
         # device tensors) referenced until the event has fired even if the caller drops this object early.
         with _INFLIGHT_LOCK:
@@ -297,11 +298,14 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
     tensors (coarse -> fine: G = S/32, S/16, S/8), bit-identical to YoloV3Layer -> YoloV3PostProcess."""
 
     def __init__(self, img_size, threshold: bool = True, anchors=ops.COCO_ANCHORS, top_k: Optional[int] = None,
-                 nan_check: str = "full"):
+                 nan_check: str = "full", tail_stream: Optional["torch.cuda.Stream"] = None):
         """nan_check="full": the reference's ValueError for a NaN anywhere in the prediction (every byte of the
         heads is read).  "survivors": threshold-first decode -- identical detections, but only objectness values
         and the rows that pass the threshold are NaN-checked, and only those are read from HBM."""
         super().__init__(decoder=_FusedYoloDecoder(img_size, threshold, anchors, nan_check), nms=True, top_k=top_k)
+        # forward_async only: NMS + packing of a batch run on this stream, behind the decode, so the caller's stream
+        # goes straight on to the next batch's pre-process (serving loops; results are identical)
+        self.tail_stream = tail_stream
 
     def n_classes_hint(self, input) -> int:
         return int(input[0].size(1)) // 3 - 5
@@ -314,8 +318,9 @@ class YoloV3FusedPostProcess(BatchedNMSPostProcess):
         def call(optimistic):
             packed, meta, host = ops.yolo_fused_postprocess(
                 input, int(d.img_size), sthr, ithr, d.threshold, d.anchors,
-                threshold_first=(d.nan_check == "survivors"), top_k=self.top_k, optimistic_nms=optimistic)
-            return PendingDetections(packed, meta, host)
+                threshold_first=(d.nan_check == "survivors"), top_k=self.top_k, optimistic_nms=optimistic,
+                tail_stream=self.tail_stream)
+            return PendingDetections(packed, meta, host, stream=self.tail_stream)
 
         # more rows per image than the single-launch NMS sorts (S >= 544): bet on few candidates, redo otherwise
         optimistic = ops.yolo_rows(int(d.img_size)) > ops.NMS_SINGLE_LAUNCH_MAX
