@@ -8,6 +8,7 @@
 // the caller supplies one workspace for every intermediate.  Saves the host ~4 marshalled calls and ~8 tensor
 // allocations per batch (the synchronous Python API is host-bound at 256 images per call).
 #include "vx_common.h"
+#include <mutex>
 
 static inline size_t vx_al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -87,6 +88,8 @@ static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float 
                                   w.scores, w.cls, w.det, counts, status, w.fused, w.fused_bytes, stream);
     if (rc != VX_OK) return rc;
     if (tail_stream != stream) {                       // NMS + packing on their own stream, behind the decode
+        static std::mutex mu;                          // record + wait as one step: the event is shared per device
+        std::lock_guard<std::mutex> lock(mu);
         hipEvent_t ev = vx_decoded_event();
         if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)tail_stream, ev, 0) != hipSuccess)
             return VX_ERR_LAUNCH;
