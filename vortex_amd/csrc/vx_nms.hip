@@ -309,6 +309,19 @@ __device__ __forceinline__ bool vx_iou_bracket(float inter, float uni, const vx_
     return hi;
 }
 
+// A box is "tame" when it is well formed (x2 >= x1, y2 >= y1) with an area in [1e-29, 1e29].  For two tame boxes
+// w <= both widths and h <= both heights (rounded differences and products are monotonic), so inter <= min(ia, ja)
+// and uni = fl(fl(ia + ja) - inter) lies in [~max(ia, ja), ia + ja] -- inside (1e-30, 1e30) -- and the bracket needs
+// no range test.
+__device__ __forceinline__ bool vx_tame(const vx_f4 &b, float area) {
+    return b.z >= b.x && b.w >= b.y && area >= 1e-29f && area <= 1e29f;
+}
+__device__ __forceinline__ bool vx_iou_bracket_tame(float inter, float uni, const vx_thr &T, bool &und) {
+    bool hi = inter > T.hi * uni, lo = inter < T.lo * uni;
+    und = und || !(hi || lo);
+    return hi;
+}
+
 template <bool IU>
 __device__ __forceinline__ bool vx_iou_gt(float ix1, float iy1, float ix2, float iy2, float ia,
                                           float jx1, float jy1, float jx2, float jy2, float ja, const vx_thr &T) {
@@ -476,6 +489,7 @@ struct vx_sweep_smem_t {
     vx_f4 kbox[2][64];
     float karea[2][64];
     int kcount[2];
+    int kwild[2];                         // some kept box of the buffer is not tame (vx_tame)
 };
 
 typedef vx_sweep_smem_t<VX_ALIVE_WORDS> vx_sweep_smem;               // multi-kernel path: any segment size
@@ -485,11 +499,12 @@ typedef vx_sweep_smem_t<VX_SORT_CHMAX / 64> vx_sweep_smem_image;      // single-
 template <class SM>
 __device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, const vx_f4 &bx, float a,
                                               bool al, const vx_thr &thr) {
-    bool sup = false, und = !thr.fast;
-    if (thr.fast) {
-        // bracket tests only, no branch inside the loop; two kept boxes per trip (independent chains, both LDS
-        // reads in flight).  A lane that meets a pair the bracket cannot decide (~1 in 10^5) repeats its loop
-        // with the division below.
+    // bracket tests only, no branch inside the loop; two kept boxes per trip (independent chains, both LDS reads
+    // in flight).  A lane that meets a pair the bracket cannot decide (~1 in 10^5), or whose own box is not tame,
+    // repeats its loop with the division below; so does everyone when the buffer holds a kept box that is not tame
+    // or the threshold is outside the bracket's range.
+    bool sup = false, und = al && (!thr.fast || S.kwild[buf] != 0 || !vx_tame(bx, a));   // dead lanes: result unused
+    if (!und) {
         int q = 0;
         for (; q + 1 < kc; q += 2) {
             vx_f4 k0 = S.kbox[buf][q], k1 = S.kbox[buf][q + 1];
@@ -497,15 +512,15 @@ __device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, cons
             float i0, u0, i1, u1;
             vx_iou_parts<false>(k0.x, k0.y, k0.z, k0.w, a0, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
             vx_iou_parts<false>(k1.x, k1.y, k1.z, k1.w, a1, bx.x, bx.y, bx.z, bx.w, a, i1, u1);
-            bool s0 = vx_iou_bracket(i0, u0, thr, und);
-            bool s1 = vx_iou_bracket(i1, u1, thr, und);
+            bool s0 = vx_iou_bracket_tame(i0, u0, thr, und);
+            bool s1 = vx_iou_bracket_tame(i1, u1, thr, und);
             sup = sup || s0 || s1;
         }
         if (q < kc) {
             vx_f4 kb = S.kbox[buf][q];
             float ka = S.karea[buf][q], i0, u0;
             vx_iou_parts<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
-            sup = vx_iou_bracket(i0, u0, thr, und) || sup;
+            sup = vx_iou_bracket_tame(i0, u0, thr, und) || sup;
         }
     }
     if (und) {
@@ -550,7 +565,8 @@ __device__ __forceinline__ void vx_resolve_tile(SM &S, const vx_f4 *__restrict__
         S.kbox[buf][pos] = bx;
         S.karea[buf][pos] = a;
     }
-    if (lane == 0) { S.alive[t] = al; S.kcount[buf] = __popcll(al); }
+    const u64 wild = __ballot(((al >> lane) & 1ull) && !vx_tame(bx, a));
+    if (lane == 0) { S.alive[t] = al; S.kcount[buf] = __popcll(al); S.kwild[buf] = wild != 0; }
 }
 
 template <class SM>
