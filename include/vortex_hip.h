@@ -35,7 +35,7 @@ extern "C" {
 
 /* bits of the device status word (int32, caller zeroes it, kernels OR into it) */
 #define VX_STATUS_NAN         1     /* predictions contain NaN: postprocess/yolov3.py:35-36 -> ValueError */
-#define VX_STATUS_BAD_CLASS   2     /* class index outside [0, VX_MAX_CLASSES) (or != 0 when n_classes == 1) */
+#define VX_STATUS_BAD_CLASS   2     /* class index outside [0, n_classes) (n_classes <= 0: [0, VX_MAX_CLASSES)) */
 #define VX_STATUS_RANGE       4     /* NMS: |box coordinate| >= 1024 with more than one class: the per-class
                                        sweep would differ from the reference's shifted single pass -> refused */
 #define VX_STATUS_DEFERRED    8     /* vx_batched_nms_small: some image had more candidates than the single-launch
@@ -155,10 +155,12 @@ int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
  *   d_keep_counts i32[B]
  * top_k > 0 truncates each keep list to its first top_k entries (build-side extension);
  * out_capacity >= min(capacity, top_k>0 ? top_k : capacity).
- * Limits: capacity <= VX_MAX_CANDIDATES, 0 <= cls < VX_MAX_CLASSES (else VX_STATUS_BAD_CLASS),
+ * Limits: capacity <= VX_MAX_CANDIDATES, 0 <= cls < n_classes <= VX_MAX_CLASSES (else VX_STATUS_BAD_CLASS),
  * |coordinate| < 1024 so that classes cannot overlap after the offset (always true for
  * normalised boxes; checked on the device -> VX_STATUS_RANGE), iou_threshold >= 0.
- * n_classes == 1 declares class-agnostic NMS (every cls must be 0): no shift, any coordinate range. */
+ * n_classes == 1 declares class-agnostic NMS (every cls must be 0): no shift, any coordinate range.
+ * n_classes is the caller's bound on the class indices (<= 0: VX_MAX_CLASSES); with 4..256 declared classes
+ * images beyond the single-launch kernel are partitioned by class before sorting (see vx_nms.hip). */
 size_t vx_batched_nms_workspace_bytes(int B, int capacity);
 int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
                    const float *d_det, const int32_t *d_counts,

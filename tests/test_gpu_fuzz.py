@@ -207,3 +207,41 @@ def test_tail_stream_pipeline_equals_single_stream():
         prev = (pend, ref)
     got, exp = prev[0].result(), prev[1]
     assert all(torch.equal(a, b) for a, b in zip(got, exp))
+
+
+@pytest.mark.parametrize("C,K,skew", [(5, 40000, True), (5, 40000, False), (256, 30000, False), (4, 17000, True),
+                                      (80, 20000, False)])
+def test_class_partitioned_path_and_its_fallback(C, K, skew):
+    """Declared class counts of 4..256 with more candidates than the single-launch kernel take the class-partitioned
+    path (count, scatter, per-class LDS sort + sweep); an image with one class beyond 16384 boxes (skew) falls back
+    to the general path inside the same call, next to an image that does not."""
+    g = torch.Generator().manual_seed(C * 1000 + K)
+    B = 2
+    boxes = torch.stack([_boxes("normal", K, g) for _ in range(B)]).contiguous()
+    scores = torch.rand(B, K, generator=g)
+    cls = torch.randint(0, C, (B, K), generator=g)
+    if skew:
+        cls[0, : int(K * 0.9)] = C - 1                    # image 0: one segment of 0.9 K boxes; image 1 stays balanced
+    det = torch.randn(B, K, 6, generator=g)
+    counts = torch.tensor([K, K - 123], dtype=torch.int32)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(DEV), 0.5, C, None)
+    assert int(status.item()) == 0
+    kc = keep_counts.cpu().tolist()
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([0.5]))
+        assert kc[b] == ref.numel() and torch.equal(keep_idx[b, :kc[b]].cpu(), ref)
+        assert torch.equal(out_det[b, :kc[b]].cpu(), det[b, :n][ref])
+
+
+def test_class_index_beyond_the_declared_count_is_reported():
+    g = torch.Generator().manual_seed(5)
+    for K in (50, 3000, 20000):                           # single-wave, single-launch, partitioned paths
+        boxes = _boxes("normal", K, g)[None].contiguous()
+        scores = torch.rand(1, K, generator=g)
+        cls = torch.randint(0, 10, (1, K), generator=g)
+        cls[0, K // 2] = 10                               # declared: 10 classes
+        det = torch.randn(1, K, 6, generator=g)
+        *_, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), None, 0.5, 10, None)
+        assert int(status.item()) & V._lib.VX_STATUS_BAD_CLASS

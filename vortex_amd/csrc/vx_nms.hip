@@ -46,11 +46,10 @@ __global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restri
     int b = blockIdx.y;
     int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
     int k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) count2[b] = 0;
+    if (k == 0 && n > 0) count2[b] = 0;              // n == 0: not this path's image (its count2 may be in use)
     if (k < n) {
         long long c = cls[(long long)b * p.cap + k];
-        if (c < 0 || c >= VX_MAX_CLASSES) { atomicOr(status, VX_STATUS_BAD_CLASS); c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
-        if (p.n_classes == 1 && c != 0) { atomicOr(status, VX_STATUS_BAD_CLASS); c = 0; }
+        if (c < 0 || c >= p.n_classes) { atomicOr(status, VX_STATUS_BAD_CLASS); c = c < 0 ? 0 : p.n_classes - 1; }
         keys1[(long long)b * p.npad_cap + k] = vx_key1((int)c, scores[(long long)b * p.cap + k], k);
     }
 }
@@ -657,6 +656,165 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
 }
 
 // ------------------------------------------------------------------------------------------------
+// Class-partitioned variant of keys -> sort -> sweep for images beyond the single-launch kernel when the caller
+// declared a moderate number of classes (VX_PART_MIN_CLASSES..VX_PART_MAX_CLASSES): instead of one bitonic sort
+// of all n keys of an image (log^2 n global/LDS passes), the candidates are counted per class, scattered into
+// per-class segments (any order) and each segment is sorted in the LDS of the workgroup that then sweeps it.
+//   vx_k_part_hist    : per-image class histogram (LDS counters, one global add per class and workgroup)
+//   vx_k_part_scatter : segment starts = exclusive scan of the histogram; keys -> keys1[b][segment]
+//   vx_k_part_sweep   : one workgroup per (class, image): LDS sort by (score desc, index), gather of the class-offset
+//                       boxes, greedy sweep (the routines of vx_k_nms_sweep), kept keys -> keys2.  Launched twice:
+//                       segments of up to VX_PART_SMALL keys (16 KiB of LDS, several workgroups per CU), then the
+//                       larger ones up to VX_SORT_CHMAX (128 KiB).
+// An image with a segment beyond VX_SORT_CHMAX is left to the general path (sel2[b] = its count).
+#define VX_PART_MIN_CLASSES 4
+#define VX_PART_MAX_CLASSES 256
+#define VX_PART_SMALL 2048
+#define VX_PART_TILE 4096
+
+struct vx_part_args {
+    vx_nms_params p;
+    const float *boxes, *scores;
+    const long long *cls;
+    const int *sel;        // [B] first-level selection: candidate count of the images left by vx_k_nms_image, else 0
+    int *hist, *cursor;    // [B][VX_PART_MAX_CLASSES], zeroed before vx_k_part_hist
+    int *segstart;         // [B][VX_PART_MAX_CLASSES + 1]
+    int *sel2;             // [B] out: count of the images handed on to the general path, else 0
+    u64 *keys1, *keys2;
+    vx_f4 *sbox;
+    float *sarea;
+    int *count2, *status;
+};
+
+__device__ __forceinline__ int vx_part_class(long long c, int n_classes, bool &bad) {
+    if (c < 0 || c >= n_classes) { bad = true; c = c < 0 ? 0 : n_classes - 1; }
+    return (int)c;
+}
+
+__global__ __launch_bounds__(1024) void vx_k_part_hist(vx_part_args a) {
+    __shared__ int s_h[VX_PART_MAX_CLASSES];
+    const int b = blockIdx.y;
+    const int n = vx_clamp_count(a.sel[b], a.p.cap);
+    const int k0 = blockIdx.x * VX_PART_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.count2[b] = 0;
+    if (k0 >= n) return;
+    const int NC = a.p.n_classes;
+    for (int c = threadIdx.x; c < NC; c += blockDim.x) s_h[c] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int k = k0 + threadIdx.x; k < min(n, k0 + VX_PART_TILE); k += blockDim.x)
+        atomicAdd(&s_h[vx_part_class(a.cls[(long long)b * a.p.cap + k], NC, bad)], 1);
+    if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
+    __syncthreads();
+    for (int c = threadIdx.x; c < NC; c += blockDim.x)
+        if (s_h[c]) atomicAdd(&a.hist[b * VX_PART_MAX_CLASSES + c], s_h[c]);
+}
+
+__global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
+    __shared__ int s_start[VX_PART_MAX_CLASSES + 1];
+    __shared__ int s_cnt[VX_PART_MAX_CLASSES];       // this workgroup's count per class, then its next free slot
+    __shared__ int s_over;
+    const int b = blockIdx.y;
+    const int n = vx_clamp_count(a.sel[b], a.p.cap);
+    const int k0 = blockIdx.x * VX_PART_TILE;
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.sel2[b] = 0;
+        return;
+    }
+    if (k0 >= n) return;
+    const int NC = a.p.n_classes;
+    const int *h = a.hist + b * VX_PART_MAX_CLASSES;
+    if (threadIdx.x == 0) s_over = 0;
+    for (int c = threadIdx.x; c < NC; c += blockDim.x) s_cnt[c] = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {                          // exclusive scan of <= 256 counters: 4 per lane
+        const int lane = threadIdx.x;
+        int v[4], tot = 0;
+        bool over = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int c = lane * 4 + q;
+            v[q] = c < NC ? h[c] : 0;
+            over |= v[q] > VX_SORT_CHMAX;
+            tot += v[q];
+        }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int c = lane * 4 + q; if (c <= NC) s_start[c] = run; run += v[q]; }
+        if (lane == 63) s_start[NC] = incl;          // NC == 256: no lane owns index 256 above
+        if (__ballot(over) != 0 && lane == 0) s_over = 1;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c <= NC; c += blockDim.x) a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c] = s_start[c];
+        if (threadIdx.x == 0) a.sel2[b] = s_over ? n : 0;
+    }
+    if (s_over) return;                              // the general path redoes this image from its inputs
+    const long long ib = (long long)b * a.p.cap;
+    const int k1 = min(n, k0 + VX_PART_TILE);
+    bool bad = false;
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x)
+        atomicAdd(&s_cnt[vx_part_class(a.cls[ib + k], NC, bad)], 1);
+    __syncthreads();
+    for (int c = threadIdx.x; c < NC; c += blockDim.x) {
+        int m = s_cnt[c];
+        s_cnt[c] = m ? s_start[c] + atomicAdd(&a.cursor[b * VX_PART_MAX_CLASSES + c], m) : 0;
+    }
+    __syncthreads();
+    u64 *kd = a.keys1 + (long long)b * a.p.npad_cap;
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        int c = vx_part_class(a.cls[ib + k], NC, bad);
+        int pos = atomicAdd(&s_cnt[c], 1);           // any order inside the segment: the segment is sorted next
+        kd[pos] = vx_key1(c, a.scores[ib + k], k);
+    }
+}
+
+template <int LDS_KEYS>
+__global__ __launch_bounds__(512) void vx_k_part_sweep(vx_part_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    __shared__ vx_sweep_smem_image S;
+    const int b = blockIdx.y, c = blockIdx.x;
+    if (a.sel[b] == 0 || a.sel2[b] != 0) return;
+    const int lo = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
+    const int len = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c + 1] - lo;
+    // this launch's share: (0, VX_PART_SMALL] or (VX_PART_SMALL, VX_SORT_CHMAX]
+    if (len <= 0 || len > LDS_KEYS || (LDS_KEYS > VX_PART_SMALL && len <= VX_PART_SMALL)) return;
+    const vx_nms_params &p = a.p;
+    const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
+    const int nt = blockDim.x;
+    const int npad = vx_next_pow2(len);
+    const u64 *kin = a.keys1 + ob + lo;
+    for (int i = threadIdx.x; i < npad; i += nt) sk[i] = i < len ? kin[i] : VX_KEY_SENTINEL;
+    __syncthreads();
+    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
+    vx_f4 *sb = a.sbox + ob + lo;
+    float *sa = a.sarea + ob + lo;
+    const float off = (float)(c * (VX_MAX_COORDINATE + 1));
+    bool oob = false;
+    for (int i = threadIdx.x; i < len; i += nt) {
+        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(sk[i])) * 4);
+        oob |= !vx_box_in_range(bx);
+        bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
+        sb[i] = bx;
+        sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
+    }
+    if (__ballot(oob) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_RANGE);
+    __syncthreads();
+    const vx_thr T = vx_make_thr(p.thr);
+    u64 *k2 = a.keys2 + ob;
+    int *c2 = a.count2 + b;
+    if (len <= 64 * VX_SWEEP_WT) {
+        if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2);
+    } else {
+        vx_sweep_block(S, sb, sa, sk, 0, len, T, k2, c2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Whole NMS of one image in ONE workgroup (capacity <= VX_SORT_CHMAX): keys are built and sorted in
 // LDS, the class-offset boxes gathered into sorted order, every class segment swept (one wave per
 // small segment, the whole workgroup per large one; segment bounds come from 64-ary searches of the
@@ -706,8 +864,7 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
     bool bad = false;
     if (lane < n) {
         long long c = a.cls[ib + lane];
-        if (c < 0 || c >= VX_MAX_CLASSES) { bad = true; c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
-        if (p.n_classes == 1 && c != 0) { bad = true; c = 0; }
+        if (c < 0 || c >= p.n_classes) { bad = true; c = c < 0 ? 0 : p.n_classes - 1; }
         key = vx_key1((int)c, a.scores[ib + lane], lane);
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
@@ -790,8 +947,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         u64 key = VX_KEY_SENTINEL;
         if (i < n) {
             long long c = a.cls[ib + i];
-            if (c < 0 || c >= VX_MAX_CLASSES) { bad = true; c = c < 0 ? 0 : VX_MAX_CLASSES - 1; }
-            if (p.n_classes == 1 && c != 0) { bad = true; c = 0; }
+            if (c < 0 || c >= p.n_classes) { bad = true; c = c < 0 ? 0 : p.n_classes - 1; }
             key = vx_key1((int)c, a.scores[ib + i], i);
         }
         sk[i] = key;
@@ -901,7 +1057,11 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
 // ------------------------------------------------------------------------------------------------
 static inline size_t vx_align256n(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct vx_nms_ws { u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel; size_t bytes; };
+struct vx_nms_ws {
+    u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel;
+    int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
+    size_t bytes;
+};
 
 static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     vx_nms_ws w;
@@ -916,6 +1076,10 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * 8 * sizeof(u64));   // per-image phase clocks (diagnostics)
     w.seg = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
     w.sel = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+    w.part_hist = (int *)(p + off); off += (size_t)B * VX_PART_MAX_CLASSES * sizeof(int);
+    w.part_cursor = (int *)(p + off); off += vx_align256n((size_t)B * VX_PART_MAX_CLASSES * sizeof(int));
+    w.part_segstart = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
+    w.sel2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.bytes = off;
     return w;
 }
@@ -1009,6 +1173,35 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         if (all_fit || small_only) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
     d_counts = w.sel;                                  // from here on: only the images the kernel above left
+
+    const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
+    if (partitioned) {
+        static bool part_attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
+        if (!part_attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *)vx_k_part_sweep<VX_SORT_CHMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
+                return VX_ERR_LAUNCH;
+            part_attr_set[dev] = true;
+        }
+        vx_part_args a;
+        a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.cls = (const long long *)d_cls; a.sel = w.sel;
+        a.hist = w.part_hist; a.cursor = w.part_cursor; a.segstart = w.part_segstart; a.sel2 = w.sel2;
+        a.keys1 = w.keys1; a.keys2 = w.keys2; a.sbox = w.sbox; a.sarea = w.sarea; a.count2 = w.count2; a.status = d_status;
+        if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
+            return VX_ERR_LAUNCH;
+        dim3 tiles((capacity + VX_PART_TILE - 1) / VX_PART_TILE, B);
+        vx_prof_begin(VX_PROF_NMS_KEYS, st);
+        hipLaunchKernelGGL(vx_k_part_hist, tiles, dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(vx_k_part_scatter, tiles, dim3(1024), 0, st, a);
+        vx_prof_end(VX_PROF_NMS_KEYS, st);
+        vx_prof_begin(VX_PROF_SWEEP, st);
+        hipLaunchKernelGGL(vx_k_part_sweep<VX_PART_SMALL>, dim3(n_classes, B), dim3(512), VX_PART_SMALL * sizeof(u64), st, a);
+        hipLaunchKernelGGL(vx_k_part_sweep<VX_SORT_CHMAX>, dim3(n_classes, B), dim3(512), VX_SORT_CHMAX * sizeof(u64), st, a);
+        vx_prof_end(VX_PROF_SWEEP, st);
+        d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
+    }
 
     vx_prof_begin(VX_PROF_NMS_KEYS, st);
     hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
