@@ -572,10 +572,14 @@ template <class SM>
 __device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ sbox,
                                                const float *__restrict__ sarea, const u64 *__restrict__ keys1,
                                                int lo, int n, const vx_thr &thr, u64 *__restrict__ keys2,
-                                               int *__restrict__ count2) {
+                                               int *__restrict__ count2, int top_k) {
+    // top_k > 0: only the first top_k kept boxes of the segment can reach the image's top_k (they precede every
+    // other kept box of their class in score order), so the sweep stops at the tile that completes them and emits
+    // no more than top_k keys -- the first top_k kept do not depend on the boxes after them.
     const int lane = vx_lane();
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int T = (n + 63) >> 6;
+    int ktot = 0, Tdone = T;
     for (int w = threadIdx.x; w < T; w += blockDim.x) {
         int rem = n - w * 64;
         S.alive[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
@@ -586,6 +590,10 @@ __device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ 
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         const int kc = S.kcount[buf];
+        if (top_k > 0) {
+            ktot += kc;
+            if (ktot >= top_k) { Tdone = t + 1; break; }      // uniform: every thread reads the same kcount
+        }
         if (wave == 0) {
             if (t + 1 < T) vx_resolve_tile(S, sbox, sarea, lo, n, t + 1, buf ^ 1, buf, kc, thr);
         } else if (kc > 0) {
@@ -602,9 +610,17 @@ __device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ 
         }
         __syncthreads();
     }
-    for (int w = wave; w < T; w += nw) {
+    for (int w = wave; w < Tdone; w += nw) {
         u64 m = S.alive[w];
         bool mine = (m >> lane) & 1ull;
+        if (top_k > 0) {                                      // rank of the tile's first kept box in the segment
+            int before = 0;
+            for (int q = lane; q < w; q += 64) before += __popcll(S.alive[q]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, VX_WAVE);
+            mine = mine && before + vx_mbcnt(m) < top_k;
+            m = __ballot(mine);
+        }
         u64 key = mine ? keys1[lo + w * 64 + lane] : 0ull;
         vx_emit_kept(m, mine, key, keys2, count2);
     }
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
     __syncthreads();
     // phase B: large segments, whole workgroup each
     const int nbig = s_nbig;
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], T, k2, c2);
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], T, k2, c2, p.top_k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(512) void vx_k_part_sweep(vx_part_args a) {
     if (len <= 64 * VX_SWEEP_WT) {
         if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2);
     } else {
-        vx_sweep_block(S, sb, sa, sk, 0, len, T, k2, c2);
+        vx_sweep_block(S, sb, sa, sk, 0, len, T, k2, c2, p.top_k);
     }
 }
 
@@ -1025,7 +1041,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __syncthreads();
     VX_STAMP(4);
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], T, k2, &s_count2);
+    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], T, k2, &s_count2, p.top_k);
     __syncthreads();
     VX_STAMP(5);
     // kept keys back into global score order, then the outputs
