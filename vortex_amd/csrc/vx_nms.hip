@@ -7,6 +7,9 @@
 //   vx_k_nms_sweep      : per (image, class segment) greedy suppression: 64x64 IoU tiles resolved
 //                         with wavefront ballots; large segments use the block-level sweep
 //                         (wave 0 resolves a tile, all waves apply its kept boxes to later tiles)
+//   vx_k_part_*         : with 4..256 declared classes the first sort is replaced by a class partition and a
+//                         per-class LDS sort inside the sweeping workgroup (see there)
+//   vx_k_nms_image      : capacity <= 16384: all of the above for one image in ONE workgroup, keys in LDS
 //   second sort         : kept boxes back into global score order (key2 = [score:32][index:32])
 //
 // Reference: networks/modules/postprocess/utils/nms.py:57-98 (batched_nms: offsets = idxs*2049
