@@ -245,3 +245,27 @@ def test_class_index_beyond_the_declared_count_is_reported():
         det = torch.randn(1, K, 6, generator=g)
         *_, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), None, 0.5, 10, None)
         assert int(status.item()) & V._lib.VX_STATUS_BAD_CLASS
+
+
+@pytest.mark.parametrize("levels", [4, 1 << 20])
+@pytest.mark.parametrize("top_k", [1, 300, 2048, 5000])
+def test_top_k_select_with_tied_scores(levels, top_k):
+    """top_k on the multi-kernel path: 30 000 disjoint boxes (all kept), scores quantised to `levels` values -- with 4
+    levels the radix select has to descend into the index bits of the keys; top_k beyond the select's limit takes the
+    full second sort."""
+    g = torch.Generator().manual_seed(levels % 97 + top_k)
+    K, C = 30000, 3
+    gx = (torch.arange(K) % 200).float() * 0.005
+    gy = (torch.arange(K) // 200).float() * 0.005
+    boxes = torch.stack((gx, gy, gx + 0.004, gy + 0.004), 1)[torch.randperm(K, generator=g)][None].contiguous()
+    scores = ((torch.rand(1, K, generator=g) * levels).floor() / levels).contiguous()
+    cls = torch.randint(0, C, (1, K), generator=g)
+    det = torch.randn(1, K, 6, generator=g)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(
+        boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), None, 0.5, C, top_k)
+    ref = O.batched_nms(boxes[0], scores[0], cls[0], torch.tensor([0.5]))
+    assert ref.numel() == K                                # nothing overlaps
+    ref = ref[:top_k]
+    assert int(status.item()) == 0 and int(keep_counts[0]) == ref.numel()
+    assert torch.equal(keep_idx[0, :ref.numel()].cpu(), ref)
+    assert torch.equal(out_det[0, :ref.numel()].cpu(), det[0][ref])

@@ -834,6 +834,95 @@ __global__ __launch_bounds__(512) void vx_k_part_sweep(vx_part_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// top_k on the multi-kernel path: instead of sorting every kept key of an image (second sort), a radix select
+// over the 64-bit keys (12-bit digits, most significant first) finds the smallest key range that holds the
+// first top_k keys and fits the LDS buffer; only those keys are sorted.  Keys are unique (the index is part of
+// the key), so the select always converges.  One workgroup per image.
+#define VX_TOPK_MAX 2048
+#define VX_TOPK_LDS 4096
+
+__global__ __launch_bounds__(1024) void vx_k_topk_select(const u64 *__restrict__ keys2, const int *__restrict__ count2,
+                                                        const int *__restrict__ sel, vx_nms_params p, vx_epi_params ep) {
+    __shared__ __attribute__((aligned(16))) u64 sk[VX_TOPK_LDS];
+    __shared__ int s_h[4096];
+    __shared__ int s_wtot[16];
+    __shared__ int s_T, s_before, s_cnt, s_n;
+    const int b = blockIdx.x, nt = blockDim.x;
+    if (sel && sel[b] == 0) return;                  // finished by vx_k_nms_image
+    const int n2 = vx_clamp_count(count2[b], p.npad_cap);
+    int want = n2;
+    if (p.top_k > 0) want = min(want, p.top_k);
+    want = min(want, p.out_cap);
+    if (threadIdx.x == 0) ep.keep_counts[b] = want;
+    if (want == 0) return;
+    const u64 *k2 = keys2 + (long long)b * p.npad_cap;
+    const int lane = vx_lane(), wave = threadIdx.x >> 6;
+    u64 prefix = 0;
+    int shift = 64, before = 0;
+    if (n2 > VX_TOPK_LDS) {
+        while (true) {
+            const int bits = min(12, shift);
+            const int hi_shift = shift;              // keys taking part: (key >> hi_shift) == prefix
+            shift -= bits;
+            const unsigned mask = (1u << bits) - 1u;
+            for (int i = threadIdx.x; i < 4096; i += nt) s_h[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n2; i += nt) {
+                u64 key = k2[i];
+                if (hi_shift == 64 || (key >> hi_shift) == prefix) atomicAdd(&s_h[(unsigned)(key >> shift) & mask], 1);
+            }
+            __syncthreads();
+            // the bin that holds the want-th key: 4 bins per thread, wave scan, wave totals
+            int v[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = s_h[threadIdx.x * 4 + q]; tot += v[q]; }
+            int incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();
+            int run = before + incl - tot;
+            for (int w = 0; w < wave; ++w) run += s_wtot[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (run < want && want <= run + v[q]) { s_T = threadIdx.x * 4 + q; s_before = run; s_cnt = v[q]; }
+                run += v[q];
+            }
+            __syncthreads();
+            prefix = (hi_shift == 64 ? 0ull : prefix << bits) | (u64)(unsigned)s_T;
+            before = s_before;
+            const int cnt = s_cnt;
+            __syncthreads();                         // s_T / s_before / s_cnt are rewritten by the next level
+            if (before + cnt <= VX_TOPK_LDS || shift == 0) break;
+        }
+    }
+    // collect the keys at or below the selected range (everything when the image's keys fit), sort, write
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n2; i += nt) {
+        u64 key = k2[i];
+        if (shift == 64 || (key >> shift) <= prefix) {
+            int pos = atomicAdd(&s_n, 1);
+            if (pos < VX_TOPK_LDS) sk[pos] = key;
+        }
+    }
+    __syncthreads();
+    const int m = min(s_n, VX_TOPK_LDS);
+    const int npad = vx_next_pow2(max(m, 1));
+    for (int i = m + threadIdx.x; i < npad; i += nt) sk[i] = VX_KEY_SENTINEL;
+    __syncthreads();
+    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    for (int i = threadIdx.x; i < want; i += nt)
+        ep.keep_idx[(long long)b * ep.out_cap + i] = (long long)(sk[i] & 0xFFFFFFFFull);
+    const float *src = ep.det + (long long)b * ep.cap * ep.D;
+    float *dst = ep.out_det + (long long)b * ep.out_cap * ep.D;
+    for (int e = threadIdx.x; e < want * ep.D; e += nt) {
+        int i = e / ep.D, q = e - i * ep.D;
+        dst[e] = src[(long long)(sk[i] & 0xFFFFFFFFull) * ep.D + q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Whole NMS of one image in ONE workgroup (capacity <= VX_SORT_CHMAX): keys are built and sorted in
 // LDS, the class-offset boxes gathered into sorted order, every class segment swept (one wave per
 // small segment, the whole workgroup per large one; segment bounds come from 64-ary searches of the
@@ -1248,7 +1337,10 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
                        w.count2);
     vx_prof_end(VX_PROF_SWEEP, st);
     vx_prof_begin(VX_PROF_SORT2, st);
-    rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
+    if (top_k > 0 && top_k <= VX_TOPK_MAX)             // only the first top_k keys are needed: select, then sort those
+        hipLaunchKernelGGL(vx_k_topk_select, dim3(B), dim3(1024), 0, st, w.keys2, w.count2, w.sel, p, ep);
+    else
+        rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
     vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
