@@ -113,7 +113,7 @@ def ragged_case(seed):
     g = torch.Generator().manual_seed(110_000 + seed)
     B = 2 + seed % 4
     cap = [900, 5000, 17500, 24000][seed % 4]
-    C = [1, 3, 80, 4096][(seed // 4) % 4]
+    C = [1, 3, 80, 4096, 20, 256, 4][(seed // 4) % 7]
     counts = torch.randint(0, cap + 1, (B,), generator=g)
     counts[0] = cap
     if B > 2:
@@ -122,8 +122,12 @@ def ragged_case(seed):
     scores = torch.rand(B, cap, generator=g)
     cls = torch.randint(0, C, (B, cap), generator=g)
     det = torch.randn(B, cap, 6, generator=g)
-    top_k = [None, 100, 1][seed % 3]
+    top_k = [None, 100, 1, 3000, 2048][seed % 5]
     thr = [0.3, 0.5, 0.7][seed % 3]
+    if seed % 11 == 0:
+        scores = (scores * 4).floor() / 4                # heavy ties: the top_k select descends into the index bits
+    if seed % 13 == 0:
+        cls[0, : cap * 3 // 4] = C - 1                    # one long segment (beyond the LDS sort when cap > 21845)
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(torch.int32).to(DEV), thr, C, top_k)
     ok = int(status.item()) == 0
