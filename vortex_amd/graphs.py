@@ -68,4 +68,4 @@ class _GraphPending(PendingDetections):
         B = (len(m) - 1) // 2
         ops.raise_on_status(int(m[-1]))
         kc = m[B:2 * B]
-        return tuple(torch.split(self.packed[:sum(kc)].clone(), kc))
+        return tuple(self.packed[:sum(kc)].clone().unsafe_split_with_sizes(kc))
