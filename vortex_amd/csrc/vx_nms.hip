@@ -81,6 +81,15 @@ __device__ __forceinline__ u64 vx_shfl_xor_u64(u64 v, int j) {
     unsigned lo = __shfl_xor((unsigned)v, j), hi = __shfl_xor((unsigned)(v >> 32), j);
     return ((u64)hi << 32) | lo;
 }
+// lane ^ 1 and lane ^ 2 stay inside a quad: DPP quad_perm moves on the VALU instead of two ds_bpermute round trips
+// through the LDS crossbar (the cross-lane steps of the register sort are bound by that crossbar)
+template <int J> __device__ __forceinline__ u64 vx_quad_xor_u64(u64 v) {
+    static_assert(J == 1 || J == 2, "quad_perm covers lane^1 and lane^2");
+    constexpr int ctrl = J == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
+    unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, ctrl, 0xF, 0xF, true);
+    unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), ctrl, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
 
 #define VX_SORT_E 4                            // keys per lane in the register pass
 #define VX_SORT_BLK (64 * VX_SORT_E)           // keys per wave in the register pass
@@ -117,14 +126,36 @@ __device__ __forceinline__ void vx_bitonic_regs(u64 *sk, int m, int base, int k_
                     }
                 }
             }
-            // cross-lane steps (j = 32 .. 1)
-            for (int j = min(k >> 1, 32); j > 0; j >>= 1) {
+            // cross-lane steps (j = 32 .. 4 through the LDS crossbar, j = 2, 1 by DPP)
+            for (int j = min(k >> 1, 32); j > 2; j >>= 1) {
                 const bool lower = (lane & j) == 0;
 #pragma unroll
                 for (int r = 0; r < VX_SORT_E; ++r) {
                     if (r < rmax) {
                         bool asc = ((base + e0 + r * 64) & k) == 0;
                         u64 o = vx_shfl_xor_u64(v[r], j);
+                        v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
+                    }
+                }
+            }
+            if (k >= 4) {
+                const bool lower = (lane & 2) == 0;
+#pragma unroll
+                for (int r = 0; r < VX_SORT_E; ++r) {
+                    if (r < rmax) {
+                        bool asc = ((base + e0 + r * 64) & k) == 0;
+                        u64 o = vx_quad_xor_u64<2>(v[r]);
+                        v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
+                    }
+                }
+            }
+            {
+                const bool lower = (lane & 1) == 0;
+#pragma unroll
+                for (int r = 0; r < VX_SORT_E; ++r) {
+                    if (r < rmax) {
+                        bool asc = ((base + e0 + r * 64) & k) == 0;
+                        u64 o = vx_quad_xor_u64<1>(v[r]);
                         v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
                     }
                 }
@@ -955,7 +986,7 @@ __device__ __forceinline__ u64 vx_wave_sort64(u64 key) {
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            u64 o = vx_shfl_xor_u64(key, j);
+            u64 o = j == 1 ? vx_quad_xor_u64<1>(key) : j == 2 ? vx_quad_xor_u64<2>(key) : vx_shfl_xor_u64(key, j);
             bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
             u64 mn = key < o ? key : o, mx = key < o ? o : key;
             key = take_min ? mn : mx;
