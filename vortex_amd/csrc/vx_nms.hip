@@ -83,6 +83,20 @@ __device__ __forceinline__ u64 vx_shfl_xor_u64(u64 v, int j) {
 }
 // lane ^ 1 and lane ^ 2 stay inside a quad: DPP quad_perm moves on the VALU instead of two ds_bpermute round trips
 // through the LDS crossbar (the cross-lane steps of the register sort are bound by that crossbar)
+// lane ^ 8 = rotation by 8 inside a row of 16 (row_ror:8); lane ^ 4 = row_shl:4 for banks 0 and 2, row_shr:4 for banks 1 and 3
+__device__ __forceinline__ unsigned vx_row_xor8(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned vx_row_xor4(unsigned v) {
+    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+}
+template <int J> __device__ __forceinline__ u64 vx_row_xor_u64(u64 v) {
+    static_assert(J == 4 || J == 8, "row-local exchanges");
+    unsigned lo = J == 8 ? vx_row_xor8((unsigned)v) : vx_row_xor4((unsigned)v);
+    unsigned hi = J == 8 ? vx_row_xor8((unsigned)(v >> 32)) : vx_row_xor4((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
 template <int J> __device__ __forceinline__ u64 vx_quad_xor_u64(u64 v) {
     static_assert(J == 1 || J == 2, "quad_perm covers lane^1 and lane^2");
     constexpr int ctrl = J == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
@@ -126,14 +140,36 @@ __device__ __forceinline__ void vx_bitonic_regs(u64 *sk, int m, int base, int k_
                     }
                 }
             }
-            // cross-lane steps (j = 32 .. 4 through the LDS crossbar, j = 2, 1 by DPP)
-            for (int j = min(k >> 1, 32); j > 2; j >>= 1) {
+            // cross-lane steps (j = 32, 16 through the LDS crossbar, j = 8 .. 1 by DPP)
+            for (int j = min(k >> 1, 32); j > 8; j >>= 1) {
                 const bool lower = (lane & j) == 0;
 #pragma unroll
                 for (int r = 0; r < VX_SORT_E; ++r) {
                     if (r < rmax) {
                         bool asc = ((base + e0 + r * 64) & k) == 0;
                         u64 o = vx_shfl_xor_u64(v[r], j);
+                        v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
+                    }
+                }
+            }
+            if (k >= 16) {
+                const bool lower = (lane & 8) == 0;
+#pragma unroll
+                for (int r = 0; r < VX_SORT_E; ++r) {
+                    if (r < rmax) {
+                        bool asc = ((base + e0 + r * 64) & k) == 0;
+                        u64 o = vx_row_xor_u64<8>(v[r]);
+                        v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
+                    }
+                }
+            }
+            if (k >= 8) {
+                const bool lower = (lane & 4) == 0;
+#pragma unroll
+                for (int r = 0; r < VX_SORT_E; ++r) {
+                    if (r < rmax) {
+                        bool asc = ((base + e0 + r * 64) & k) == 0;
+                        u64 o = vx_row_xor_u64<4>(v[r]);
                         v[r] = ((asc == lower) == (o < v[r])) ? o : v[r];
                     }
                 }
@@ -986,7 +1022,8 @@ __device__ __forceinline__ u64 vx_wave_sort64(u64 key) {
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            u64 o = j == 1 ? vx_quad_xor_u64<1>(key) : j == 2 ? vx_quad_xor_u64<2>(key) : vx_shfl_xor_u64(key, j);
+            u64 o = j == 1 ? vx_quad_xor_u64<1>(key) : j == 2 ? vx_quad_xor_u64<2>(key) : j == 4 ? vx_row_xor_u64<4>(key)
+                    : j == 8 ? vx_row_xor_u64<8>(key) : vx_shfl_xor_u64(key, j);
             bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
             u64 mn = key < o ? key : o, mx = key < o ? o : key;
             key = take_min ? mn : mx;
