@@ -83,6 +83,8 @@ __device__ __forceinline__ u64 vx_shfl_xor_u64(u64 v, int j) {
 }
 // lane ^ 1 and lane ^ 2 stay inside a quad: DPP quad_perm moves on the VALU instead of two ds_bpermute round trips
 // through the LDS crossbar (the cross-lane steps of the register sort are bound by that crossbar)
+// (lane ^ 16 / lane ^ 32 stay on ds_bpermute: gfx950's v_permlane16/32_swap + select was measured slower here, 58 k vs
+// 51 k cycles for the 4096-key sort -- the sort is then VALU-bound and loses the overlap with the LDS crossbar.)
 // lane ^ 8 = rotation by 8 inside a row of 16 (row_ror:8); lane ^ 4 = row_shl:4 for banks 0 and 2, row_shr:4 for banks 1 and 3
 __device__ __forceinline__ unsigned vx_row_xor8(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
