@@ -32,6 +32,7 @@ extern "C" {
 #define VX_ERR_WORKSPACE     (-3)   /* workspace smaller than *_workspace_bytes()       */
 #define VX_ERR_LAUNCH        (-4)   /* hipGetLastError() != hipSuccess after a launch    */
 #define VX_ERR_ALIGNMENT     (-5)   /* a device pointer is not aligned as documented     */
+#define VX_ERR_SCRATCH_LIMIT (-6)   /* vx_batched_nms_noalloc: the call needs more than the static scratch holds */
 
 /* bits of the device status word (int32, caller zeroes it, kernels OR into it) */
 #define VX_STATUS_NAN         1     /* predictions contain NaN: postprocess/yolov3.py:35-36 -> ValueError */
@@ -199,6 +200,21 @@ int vx_batched_nms_small(const float *d_boxes, const float *d_scores, const int6
                          int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
                          int out_capacity, int32_t *d_status,
                          void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Allocation-free variant of vx_batched_nms (same arguments minus the workspace, same results).  It has NO
+ * counterpart in the reference; it exists for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The workspace is a static device array of
+ * vx_batched_nms_noalloc_max_bytes() = 64 MiB per GPU (held until the process ends); a call whose
+ * vx_batched_nms_workspace_bytes(B, capacity) exceeds it returns VX_ERR_SCRATCH_LIMIT (e.g. B <= 110 at
+ * capacity 10647, B <= 27 at capacity 50400).  The call itself performs no hipMalloc / hipFree; the first call
+ * on a device looks the array's address up (make it outside graph capture).  All calls on one GPU share the
+ * array: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+size_t vx_batched_nms_noalloc_max_bytes(void);
+int vx_batched_nms_noalloc(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
+                           const float *d_det, const int32_t *d_counts,
+                           int B, int capacity, int D, int n_classes, float iou_threshold, int top_k,
+                           int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
+                           int out_capacity, int32_t *d_status, void *stream);
 
 /* ---------------------------------------------------------------- tuple packing
  * The `tuple(results)` of BatchedNMSPostProcess.forward (base_postprocess.py:131-138) as one launch:

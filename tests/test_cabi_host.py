@@ -53,6 +53,9 @@ def test_argument_checks_return_codes_without_gpu():
     assert lib.vx_batched_nms(p, p, p, p, None, 1, 10, 6, 0, -0.5, 0, p, p, p, 10, p, p, 1 << 30, None) == -2
     assert lib.vx_batched_nms(p, p, p, p, None, 1, 10, 6, 0, 0.5, 0, p, p, p, 5, p, p, 1 << 30, None) == -1
     assert lib.vx_batched_nms(p, p, p, p, None, 1, 10, 6, 0, 0.5, 0, p, p, p, 10, p, p, 16, None) == -3
+    # allocation-free NMS: a call beyond the 64 MiB static scratch is refused on the host
+    assert lib.vx_batched_nms_noalloc(p, p, p, p, None, 256, 10647, 6, 80, 0.5, 0, p, p, p, 10647, p, None) == -6
+    assert lib.vx_batched_nms_noalloc(p, p, p, p, None, 0, 10, 6, 80, 0.5, 0, p, p, p, 10, p, None) == -1
     assert lib.vx_prior_decode(p, p, 1, 100, 5, 1, 0.1, 0.2, 0.5, 1, p, p, p, p, p, p, p, 1 << 30, None) == -1
     assert lib.vx_prior_decode(p, p, 1, 100, 5, 80, 0.1, 0.2, 0.5, 1, p, p, p, p, p, p, p, 1 << 30, None) == -2
 

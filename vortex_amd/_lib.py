@@ -60,6 +60,10 @@ _SIGNATURES = {
     "vx_batched_nms_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "vx_batched_nms_noalloc_max_bytes": (c_size_t, []),
+    "vx_batched_nms_noalloc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p]),
     "vx_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p]),
     "vx_format_results": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32),

@@ -11,6 +11,7 @@ extern "C" const char *vx_error_string(int code) {
         case VX_ERR_WORKSPACE: return "workspace smaller than the matching *_workspace_bytes() query";
         case VX_ERR_LAUNCH: return "HIP reported an error for a kernel launch";
         case VX_ERR_ALIGNMENT: return "a device pointer is not aligned as include/vortex_hip.h requires";
+        case VX_ERR_SCRATCH_LIMIT: return "vx_batched_nms_noalloc: B * pow2ceil(capacity) needs more than the 64 MiB static scratch";
         default: return "unknown libvortex_hip error code";
     }
 }

@@ -1439,6 +1439,50 @@ extern "C" int vx_batched_nms_small(const float *d_boxes, const float *d_scores,
 }
 
 // ------------------------------------------------------------------------------------------------
+// vx_batched_nms_noalloc: the same call for callers that cannot allocate (HIP graph capture, tight serving loops,
+// harnesses that forbid hipMalloc).  The workspace of vx_batched_nms lives in a file-scope device array; every GPU
+// the library runs on holds its own copy at its own address until the process ends, so the address is looked up
+// once per device (hipGetSymbolAddress) and only that pointer is ever handed to kernels / memsets -- the array's
+// name is a host-side stand-in, not a device address.
+#define VX_NOALLOC_SCRATCH_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char vx_nms_scratch[VX_NOALLOC_SCRATCH_BYTES];
+
+#include <mutex>
+static int vx_noalloc_scratch(void **out) {
+    static std::mutex mu;
+    static void *ptr[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {                                   // set-up: first call on this device (with it current)
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(vx_nms_scratch)) != hipSuccess || !p) return VX_ERR_LAUNCH;
+        ptr[dev] = p;
+    }
+    *out = ptr[dev];
+    return VX_OK;
+}
+
+extern "C" size_t vx_batched_nms_noalloc_max_bytes(void) { return VX_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int vx_batched_nms_noalloc(const float *d_boxes, const float *d_scores, const int64_t *d_cls, const float *d_det,
+                                      const int32_t *d_counts, int B, int capacity, int D, int n_classes,
+                                      float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
+                                      int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *stream) {
+    if (B <= 0 || capacity <= 0) return VX_ERR_INVALID_ARG;
+    if (capacity > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
+    const size_t need = vx_nms_carve(nullptr, B, vx_next_pow2(capacity)).bytes;
+    if (need > VX_NOALLOC_SCRATCH_BYTES) return VX_ERR_SCRATCH_LIMIT;      // B * pow2ceil(capacity) too large
+    void *scratch = nullptr;
+    int rc = vx_noalloc_scratch(&scratch);
+    if (rc != VX_OK) return rc;
+    // every word of the scratch that a kernel expects to start at zero (count2, the class histogram and cursors) is
+    // cleared by vx_nms_impl itself on each call; the rest is written before it is read
+    return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
+                       d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, scratch, need, stream, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tuple packing (the `tuple(results)` of base_postprocess.py:131-138 without B Python slices):
 // rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
 #define VX_PACK_ROWS 2048
