@@ -279,9 +279,15 @@ int vx_profile_select(unsigned slot_mask);
 int vx_profile_disable(void);
 int vx_profile_slots(void);
 int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, float *min_ms, float *max_ms);
+/* NMS throughput leg of the measurement: while d_counter (a caller-owned, zeroed, 8-byte aligned device word) is
+ * set, the NMS sweeps add the number of IoU tests they execute on live lanes to it (one atomic add per wave and
+ * class segment); NULL switches the counting off (the default).  Process-global, like the hooks above. */
+int vx_profile_set_iou_counter(uint64_t *d_counter);
 /* Diagnostics of the single-launch NMS kernel: while profiling is enabled, workgroup b writes 8 shader-clock
- * stamps (keys, sort, gather, wave sweeps, block sweeps, second sort, output) as u64[B][8] at this byte offset of
- * the workspace handed to vx_batched_nms (0 if the arguments are out of range). */
+ * stamps (keys, sort, gather, wave sweeps, block sweeps, second sort, output) as the first 8 words of u64[B][136] at
+ * this byte offset of the workspace handed to vx_batched_nms (0 if the arguments are out of range); words 8.. hold,
+ * per wave of the image's last column-owner sweep, cycles spent waiting / applying / on the chain / building rows,
+ * total cycles and IoU tests. */
 size_t vx_batched_nms_stamps_offset(int B, int capacity);
 
 #ifdef __cplusplus

@@ -30,7 +30,7 @@ for it in range(3):
     assert rc == 0
 torch.cuda.synchronize()
 off = lib.vx_batched_nms_stamps_offset(B, K)
-st = ws[off:off + B * 64].view(torch.int64).view(B, 8).cpu().double()
+st = ws[off:off + B * 136 * 8].view(torch.int64).view(B, 136)[:, :8].cpu().double()
 d = (st[:, 1:] - st[:, :-1])
 names = ["keys", "sort1", "gather", "sweep-wave", "sweep-block", "load+sort2", "output"]
 print("candidates/img %.0f kept/img %.0f" % (c.counts.float().mean(), c.keep_counts.float().mean()))

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Phase breakdown of vx_k_nms_image on the prior-box configs (RetinaFace b128 / FPN-SSD b64 candidates)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+from bench_configs import make_priors  # noqa: E402
+from vortex_amd import _lib as L, ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "retinaface"
+B, Lm, NL, sthr = (128, 5, 2, 0.5) if which == "retinaface" else (64, 0, 21, 0.3)
+P = 50400
+priors = make_priors(640).to(dev)
+g = torch.Generator(device=dev).manual_seed(5)
+x = torch.randn(B, P, 4 + 2 * Lm + NL, generator=g, device=dev)
+x[..., 4 + 2 * Lm + 1:] = x[..., 4 + 2 * Lm + 1:] * 2 - 3
+c = ops.prior_decode(x, priors, Lm, sthr)
+lib = L.lib()
+K = c.R
+D = c.D
+nb = lib.vx_batched_nms_workspace_bytes(B, K)
+ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+keep_idx = torch.empty((B, K), dtype=torch.int64, device=dev)
+out_det = torch.empty((B, K, D), device=dev)
+L.profile_enable(64)
+for it in range(3):
+    rc = lib.vx_batched_nms(c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(), c.det.data_ptr(),
+                            c.counts.data_ptr(), B, K, D, NL - 1, 0.4, 0, keep_idx.data_ptr(), out_det.data_ptr(),
+                            c.keep_counts.data_ptr(), K, c.status.data_ptr(), ws.data_ptr(), nb, L.stream_ptr(dev))
+    assert rc == 0
+torch.cuda.synchronize()
+print({k: round(v["avg_ms"], 4) for k, v in L.profile_read().items()})
+off = lib.vx_batched_nms_stamps_offset(B, K)
+SW = 136
+allw = ws[off:off + B * SW * 8].view(torch.int64).view(B, SW).cpu().double()
+st = allw[:, :8]
+wv = allw[:, 8:].view(B, 16, 8)
+print("per-wave cycles of the column-owner sweep, image 0: [wait, apply, chain, rows, total, tests]")
+for w_ in range(16):
+    print("  wave %2d " % w_, [int(v) for v in wv[0, w_, :6]])
+print("mean over images and waves:", [int(v) for v in wv[:, :, :6].mean(dim=(0, 1))])
+d = (st[:, 1:] - st[:, :-1])
+names = ["keys", "sort1", "gather", "sweep-wave", "sweep-block", "load+sort2", "output"]
+print("candidates/img %.0f (max %d) kept/img %.0f" % (c.counts.float().mean(), int(c.counts.max()), c.keep_counts.float().mean()))
+tot = (st[:, 7] - st[:, 0])
+print("total ticks: mean %.0f max %.0f" % (tot.mean(), tot.max()))
+for i, n in enumerate(names):
+    print("%-12s mean %8.0f  max %8.0f  share %.1f%%" % (n, d[:, i].mean(), d[:, i].max(), 100 * d[:, i].mean() / tot.mean()))

@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvortex_hip.so")
+LIB_PATH = os.environ.get("VORTEX_HIP_LIB") or os.path.join(_HERE, "lib", "libvortex_hip.so")   # override: A/B builds
 
 VX_OK = 0
 VX_STATUS_NAN = 1
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vx_profile_select": (c_int, [ctypes.c_uint]),
     "vx_profile_disable": (c_int, []),
     "vx_profile_slots": (c_int, []),
+    "vx_profile_set_iou_counter": (c_int, [c_void_p]),
     "vx_batched_nms_stamps_offset": (c_size_t, [c_int, c_int]),
     "vx_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_int),
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),

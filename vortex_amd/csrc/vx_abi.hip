@@ -95,3 +95,12 @@ extern "C" int vx_profile_get(int slot, const char **name, int *launches, float 
     *total_ms = tot; *min_ms = s.launches ? mn : 0.f; *max_ms = mx;
     return VX_OK;
 }
+
+// caller-owned device word the NMS sweeps add their executed IoU tests to (nullptr = off, the default)
+static unsigned long long *g_iou_counter = nullptr;
+unsigned long long *vx_iou_counter() { return g_iou_counter; }
+extern "C" int vx_profile_set_iou_counter(uint64_t *d_counter) {
+    if ((uintptr_t)d_counter & 7) return VX_ERR_ALIGNMENT;
+    g_iou_counter = (unsigned long long *)d_counter;
+    return VX_OK;
+}

@@ -24,6 +24,7 @@
 #include "vx_profile.h"
 
 #define VX_SORT_CHMAX 16384
+#define VX_STAMP_WORDS (8 + 16 * 8)     // per image: 8 phase stamps of vx_k_nms_image + 8 words per wave of its last column-owner sweep
 #define VX_SWEEP_WT 4                 // wave routine: segments up to 64*WT boxes
 #define VX_ALIVE_WORDS 2048           // block routine: segments up to 64*2048 = 131072 boxes
 #define VX_SWEEP_MAXBIG 128           // large segments queued per workgroup (>= classes per workgroup)
@@ -549,151 +550,297 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
     }
 }
 
-// Block routine: any segment up to 64*VX_ALIVE_WORDS boxes, software-pipelined over 64-box tiles.
-// In step t the kept boxes of tile t (parked in LDS, double-buffered) are applied by waves 1.. to
-// their share of tiles t+2.., while wave 0 applies them to tile t+1 and then resolves tile t+1
-// against itself (serial over its still-alive boxes, one ballot each) — the serial resolve is
-// hidden behind the parallel apply, one barrier per tile.
-template <int WORDS>
-struct vx_sweep_smem_t {
-    u64 alive[WORDS];
-    vx_f4 kbox[2][64];
-    float karea[2][64];
-    int kcount[2];
-    int kwild[2];                         // some kept box of the buffer is not tame (vx_tame)
+// ------------------------------------------------------------------------------------------------
+// Chain sweep: a class segment of n > 256 boxes (score order; class-offset boxes in global memory, sbox), the whole
+// workgroup (W waves, a power of two).  Tile u (64 boxes) belongs to wave u % W.  The greedy order is a chain over
+// tiles: the owner of tile t+1 applies the kept boxes of tile t to it, resolves it with a scalar bit walk over the
+// tile's precomputed suppression rows (lane i = row i: later boxes of the tile that box i suppresses; built ahead of
+// time, off the chain), writes the kept boxes compacted into an LDS ring slot and publishes (S.alive[t+1] now holds
+// the kept mask; then S.ready).  Every wave consumes the published tiles in order and applies them to its own later
+// tiles, two tiles at a time (boxes streamed from L2 one pair ahead, alive masks in LDS), whenever it gets there.
+// No workgroup barrier inside the sweep and the resolver role rotates, so the load balances itself.  Waiting waves
+// poll S.ready in LDS; a wave's progress depends on earlier tiles only and all waves of a workgroup are resident,
+// so the chain always advances; every wave leaves the loop when S.ready reaches the tile count (last tile resolved,
+// or the top_k stop) or when it has no tile left.  The ring is 2W tiles deep: a wave is at most W+1 tiles behind
+// the chain (the chain needs it every W tiles), so a slot is never rewritten while somebody still reads it.
+//
+// IoU test of the apply loop (12 VALU): for two tame boxes (vx_tame) "inter1 < lo*uni1" with the height left
+// unclamped proves the reference's predicate false (h < 0: inter1 <= 0 < lo*uni1; h >= 0: the bracket's own "lo"
+// side).  Four kept boxes per trip: their candidate values (inter1 - lo*uni1) are max-reduced per lane, so a tile
+// costs 4 x 12 VALU + one ballot and one scalar branch per trip (tools/micro/sweep_loop.hip: 1.4-1.7x the lane-tests
+// per clock of a branch per pair); only lanes that fail the cheap test -- each box about once, when it dies -- repeat
+// the trip with the exact routine (vx_iou_gt: bracket, then the IEEE division), as do untame lanes, tiles with a wild
+// kept box, or a threshold outside the bracket's range.
+#define VX_ASYNC_TRIP 4
+
+template <int MAXTILES>
+struct vx_async_smem_t {
+    u64 alive[MAXTILES];                       // tile not resolved yet: lanes still alive; resolved: the kept mask
+    unsigned char wild[MAXTILES];              // some kept box of the tile is not tame
+    int ready;                                 // tiles resolved so far; the tile count once the sweep is over
+    int ndone;                                 // tiles whose kept mask is final (== ready unless the top_k stop hit)
+    int ktot;
 };
+typedef vx_async_smem_t<VX_SORT_CHMAX / 64> vx_async_smem;          // single-launch / partitioned paths: <= 16384 boxes
+typedef vx_async_smem_t<2048> vx_async_smem_big;                    // general path: <= 131072 boxes per segment
+// LDS ring of compacted kept boxes: 2W tiles x 64 x (16 + 4) bytes (+ one trip of overshoot for the loop's prefetch)
+__host__ __device__ __forceinline__ size_t vx_async_ring_bytes(int waves) { return ((size_t)2 * waves * 64 + 8) * 20; }
 
-typedef vx_sweep_smem_t<VX_ALIVE_WORDS> vx_sweep_smem;               // multi-kernel path: any segment size
-typedef vx_sweep_smem_t<VX_SORT_CHMAX / 64> vx_sweep_smem_image;      // single-launch path: <= 16384 boxes
-
-// lane's survival after the kc kept boxes of buffer `buf`
-template <class SM>
-__device__ __forceinline__ bool vx_apply_kept(const SM &S, int buf, int kc, const vx_f4 &bx, float a,
-                                              bool al, const vx_thr &thr) {
-    // bracket tests only, no branch inside the loop; two kept boxes per trip (independent chains, both LDS reads
-    // in flight).  A lane that meets a pair the bracket cannot decide (~1 in 10^5), or whose own box is not tame,
-    // repeats its loop with the division below; so does everyone when the buffer holds a kept box that is not tame
-    // or the threshold is outside the bracket's range.
-    bool sup = false, und = al && (!thr.fast || S.kwild[buf] != 0 || !vx_tame(bx, a));   // dead lanes: result unused
-    if (!und) {
-        int q = 0;
-        for (; q + 1 < kc; q += 2) {
-            vx_f4 k0 = S.kbox[buf][q], k1 = S.kbox[buf][q + 1];
-            float a0 = S.karea[buf][q], a1 = S.karea[buf][q + 1];
-            float i0, u0, i1, u1;
-            vx_iou_parts<false>(k0.x, k0.y, k0.z, k0.w, a0, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
-            vx_iou_parts<false>(k1.x, k1.y, k1.z, k1.w, a1, bx.x, bx.y, bx.z, bx.w, a, i1, u1);
-            bool s0 = vx_iou_bracket_tame(i0, u0, thr, und);
-            bool s1 = vx_iou_bracket_tame(i1, u1, thr, und);
-            sup = sup || s0 || s1;
-        }
-        if (q < kc) {
-            vx_f4 kb = S.kbox[buf][q];
-            float ka = S.karea[buf][q], i0, u0;
-            vx_iou_parts<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
-            sup = vx_iou_bracket_tame(i0, u0, thr, und) || sup;
-        }
-    }
-    if (und) {
-        sup = false;
-        for (int q = 0; q < kc; ++q) {
-            vx_f4 kb = S.kbox[buf][q];
-            float ka = S.karea[buf][q], i0, u0;
-            vx_iou_parts<false>(kb.x, kb.y, kb.z, kb.w, ka, bx.x, bx.y, bx.z, bx.w, a, i0, u0);
-            sup = sup || (i0 / u0) > thr.thr;
-        }
-    }
-    return al && !sup;
+__device__ __forceinline__ u64 vx_uniform64(u64 v) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
 }
 
-// wave 0: tile t (already hit by every earlier kept box except those in `prev_buf`, if any) ->
-// final kept mask, kept boxes parked in buffer `buf`
-template <class SM>
-__device__ __forceinline__ void vx_resolve_tile(SM &S, const vx_f4 *__restrict__ sbox,
-                                                const float *__restrict__ sarea, int lo, int n, int t, int buf,
-                                                int prev_buf, int prev_kc, const vx_thr &thr) {
-    const int lane = vx_lane();
-    int o = t * 64 + lane;
-    vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
-    float a = 0.f;
-    if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
-    u64 al = S.alive[t];
-    if (prev_kc > 0 && al != 0) {
-        bool mine = (al >> lane) & 1ull;
-        al = __ballot(vx_apply_kept(S, prev_buf, prev_kc, bx, a, mine, thr));
-    }
-    u64 todo = al;
-    while (todo) {
-        int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-        float bx1 = vx_bcast(bx.x, i), by1 = vx_bcast(bx.y, i);
-        float bx2 = vx_bcast(bx.z, i), by2 = vx_bcast(bx.w, i), ba = vx_bcast(a, i);
-        bool sup = (lane > i) && vx_iou_gt<true>(bx1, by1, bx2, by2, ba, bx.x, bx.y, bx.z, bx.w, a, thr);
-        al &= ~__ballot(sup);
-        todo = al & ~((2ull << i) - 1ull);
-    }
-    if ((al >> lane) & 1ull) {
-        int pos = vx_mbcnt(al);
-        S.kbox[buf][pos] = bx;
-        S.karea[buf][pos] = a;
-    }
-    const u64 wild = __ballot(((al >> lane) & 1ull) && !vx_tame(bx, a));
-    if (lane == 0) { S.alive[t] = al; S.kcount[buf] = __popcll(al); S.kwild[buf] = wild != 0; }
+__device__ __forceinline__ float vx_async_cand(const vx_f4 &K, float ka, const vx_f4 &bx, float a, float lo) {
+    float xx1 = vx_vmax<false>(K.x, bx.x);
+    float yy1 = vx_vmax<false>(K.y, bx.y);
+    float xx2 = vx_vmin<false>(K.z, bx.z);
+    float yy2 = vx_vmin<false>(K.w, bx.w);
+    float w = vx_vmax<false>(xx2 - xx1, 0.0f);
+    float inter = w * (yy2 - yy1);
+    float uni = ka + a - inter;
+    return inter - lo * uni;
 }
 
-template <class SM>
-__device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ sbox,
-                                               const float *__restrict__ sarea, const u64 *__restrict__ keys1,
-                                               int lo, int n, const vx_thr &thr, u64 *__restrict__ keys2,
-                                               int *__restrict__ count2, int top_k) {
-    // top_k > 0: only the first top_k kept boxes of the segment can reach the image's top_k (they precede every
-    // other kept box of their class in score order), so the sweep stops at the tile that completes them and emits
-    // no more than top_k keys -- the first top_k kept do not depend on the boxes after them.
-    const int lane = vx_lane();
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int T = (n + 63) >> 6;
-    int ktot = 0, Tdone = T;
-    for (int w = threadIdx.x; w < T; w += blockDim.x) {
-        int rem = n - w * 64;
-        S.alive[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-    }
-    __syncthreads();
-    if (wave == 0) vx_resolve_tile(S, sbox, sarea, lo, n, 0, 0, 0, 0, thr);
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        const int kc = S.kcount[buf];
-        if (top_k > 0) {
-            ktot += kc;
-            if (ktot >= top_k) { Tdone = t + 1; break; }      // uniform: every thread reads the same kcount
-        }
-        if (wave == 0) {
-            if (t + 1 < T) vx_resolve_tile(S, sbox, sarea, lo, n, t + 1, buf ^ 1, buf, kc, thr);
-        } else if (kc > 0) {
-            for (int u = t + 2 + (wave - 1); u < T; u += nw - 1) {
-                u64 au = S.alive[u];
-                if (au == 0) continue;
-                int o = u * 64 + lane;
-                vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
-                float a = 0.f;
-                if (o < n) { bx = sbox[lo + o]; a = sarea[lo + o]; }
-                u64 m = __ballot(vx_apply_kept(S, buf, kc, bx, a, (au >> lane) & 1ull, thr));
-                if (lane == 0) S.alive[u] = m;
+// lanes of `am` that the wave-uniform box K suppresses (one pair at a time: the row builder)
+__device__ __forceinline__ u64 vx_async_test(const vx_f4 &K, float ka, bool kwild, const vx_f4 &bx, float a, u64 unt,
+                                             u64 am, const vx_thr &T) {
+    u64 slow = __ballot(!(vx_async_cand(K, ka, bx, a, T.lo) < 0.0f));
+    slow = (kwild || !T.fast) ? am : ((slow | unt) & am);
+    u64 sup = 0;
+    if (slow) sup = __ballot(vx_iou_gt<false>(K.x, K.y, K.z, K.w, ka, bx.x, bx.y, bx.z, bx.w, a, T)) & slow;
+    return sup;
+}
+
+// kept boxes of a ring slot (kc of them, padded to whole trips with boxes that meet nothing) -> N column tiles
+template <int N>
+__device__ __forceinline__ void vx_async_apply(const vx_f4 *kb, const float *kar, int kc, bool all_slow, const vx_f4 *bx,
+                                               const float *ar, u64 *alive, const u64 *unt, const vx_thr &T) {
+    vx_f4 K[VX_ASYNC_TRIP], Kn[VX_ASYNC_TRIP];
+    vx_v4 ka, kan;
+#pragma unroll
+    for (int q = 0; q < VX_ASYNC_TRIP; ++q) K[q] = kb[q];
+    ka = *reinterpret_cast<const vx_v4 *>(kar);
+    for (int j = 0; j < kc; j += VX_ASYNC_TRIP) {
+#pragma unroll
+        for (int q = 0; q < VX_ASYNC_TRIP; ++q) Kn[q] = kb[j + VX_ASYNC_TRIP + q];       // the ring is padded for this overshoot
+        kan = *reinterpret_cast<const vx_v4 *>(kar + j + VX_ASYNC_TRIP);
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            float m = vx_async_cand(K[0], ka.x, bx[s], ar[s], T.lo);
+            m = vx_vmax<false>(m, vx_async_cand(K[1], ka.y, bx[s], ar[s], T.lo));
+            m = vx_vmax<false>(m, vx_async_cand(K[2], ka.z, bx[s], ar[s], T.lo));
+            m = vx_vmax<false>(m, vx_async_cand(K[3], ka.w, bx[s], ar[s], T.lo));
+            u64 slow = __ballot(!(m < 0.0f));
+            slow = all_slow ? alive[s] : ((slow | unt[s]) & alive[s]);
+            if (slow) {
+                // rare (about once per box, when it dies): the exact predicate for the trip's boxes -- bracket first, the
+                // IEEE division only for a pair the bracket cannot decide.  The padding boxes of a last trip meet
+                // nothing: inter == 0 fails every form of the test.
+                const float kaq[VX_ASYNC_TRIP] = {ka.x, ka.y, ka.z, ka.w};
+                bool sup = false, und = false;
+                float in_[VX_ASYNC_TRIP], un_[VX_ASYNC_TRIP];
+#pragma unroll
+                for (int q = 0; q < VX_ASYNC_TRIP; ++q) {
+                    vx_iou_parts<false>(K[q].x, K[q].y, K[q].z, K[q].w, kaq[q], bx[s].x, bx[s].y, bx[s].z, bx[s].w, ar[s],
+                                        in_[q], un_[q]);
+                    sup = vx_iou_bracket(in_[q], un_[q], T, und) || sup;
+                }
+                if (__ballot(und && ((slow >> vx_lane()) & 1ull)) != 0ull || !T.fast) {
+                    sup = false;
+#pragma unroll
+                    for (int q = 0; q < VX_ASYNC_TRIP; ++q) sup = sup || (in_[q] / un_[q]) > T.thr;
+                }
+                alive[s] &= ~(__ballot(sup) & slow);
             }
         }
-        __syncthreads();
-    }
-    for (int w = wave; w < Tdone; w += nw) {
-        u64 m = S.alive[w];
-        bool mine = (m >> lane) & 1ull;
-        if (top_k > 0) {                                      // rank of the tile's first kept box in the segment
-            int before = 0;
-            for (int q = lane; q < w; q += 64) before += __popcll(S.alive[q]);
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, VX_WAVE);
-            mine = mine && before + vx_mbcnt(m) < top_k;
-            m = __ballot(mine);
+        for (int q = 0; q < VX_ASYNC_TRIP; ++q) K[q] = Kn[q];
+        ka = kan;
+    }
+}
+
+// ring = vx_async_ring_bytes(W) bytes of LDS (16-byte aligned).  n <= 64 * MAXTILES.  Ends synchronised with the
+// segment's kept masks in S.alive[0 .. S.ndone) (cut to the first top_k kept boxes when top_k > 0).
+template <int MAXTILES>
+__device__ __forceinline__ void vx_sweep_async(vx_async_smem_t<MAXTILES> &S, void *ring, const vx_f4 *__restrict__ sbox,
+                                               int n, const vx_thr &T, int top_k, unsigned long long *iou_count,
+                                               u64 *dbg = nullptr) {
+    // wave-uniform values are made so explicitly (readfirstlane): the compiler treats threadIdx.x >> 6 and LDS loads
+    // as divergent, and the masks / loop bounds derived from them would end up in vector registers
+    const int lane = vx_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6;
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int NT = (n + 63) >> 6;
+    const int RT = 2 * W;                                         // ring depth in tiles
+    vx_f4 *rbox = reinterpret_cast<vx_f4 *>(ring);
+    float *rar = reinterpret_cast<float *>(rbox + RT * 64 + 8);
+    const bool all_slow0 = !T.fast;
+    __syncthreads();                                              // S and the ring's LDS are free again
+    for (int i = threadIdx.x; i < NT; i += blockDim.x) {
+        const int rem = n - i * 64;
+        S.alive[i] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+        S.wild[i] = 0;
+    }
+    if (threadIdx.x == 0) { S.ready = 0; S.ndone = 0; S.ktot = 0; }
+    __syncthreads();
+    unsigned long long tests = 0ull;
+    // the next tile this wave resolves: its boxes, areas, untame lanes and suppression rows stay in registers
+    int nxt = w;
+    vx_f4 bxn = {0.f, 0.f, 0.f, 0.f};
+    float arn = 0.f;
+    u64 untn = 0ull;
+    unsigned row_lo = 0u, row_hi = 0u;
+    auto load_tile = [&](int u) __attribute__((always_inline)) -> vx_f4 {
+        const int o = u * 64 + lane;
+        vx_f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (u < NT && o < n) b = sbox[o];
+        return b;
+    };
+    // rows of tile nxt (only those of still-alive boxes: the others are never read)
+    auto make_rows = [&]() __attribute__((always_inline)) {
+        bxn = load_tile(nxt);
+        arn = (bxn.z - bxn.x) * (bxn.w - bxn.y);
+        row_lo = 0u; row_hi = 0u;
+        if (nxt >= NT) return;
+        const u64 al = vx_uniform64(S.alive[nxt]);
+        untn = __ballot(!vx_tame(bxn, arn)) & al;
+        u64 todo = al;
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if (todo == 0ull) break;                              // the last alive box has nobody behind it
+            vx_f4 K;
+            K.x = vx_bcast(bxn.x, i); K.y = vx_bcast(bxn.y, i); K.z = vx_bcast(bxn.z, i); K.w = vx_bcast(bxn.w, i);
+            const float ka = vx_bcast(arn, i);
+            const u64 m = vx_async_test(K, ka, (untn >> i) & 1ull, bxn, arn, untn, todo, T);
+            if (lane == i) { row_lo = (unsigned)m; row_hi = (unsigned)(m >> 32); }
         }
-        u64 key = mine ? keys1[lo + w * 64 + lane] : 0ull;
+        const unsigned long long na = __popcll(al);
+        tests += na * (na - (na ? 1 : 0)) / 2;
+    };
+    // tile t (= nxt), every earlier kept box applied (alive mask a): greedy inside the tile, publish
+    auto resolve = [&](int t, u64 a) __attribute__((always_inline)) {
+        u64 todo = a;
+        while (todo) {
+            const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            const u64 ri = ((u64)(unsigned)__builtin_amdgcn_readlane((int)row_hi, i) << 32) |
+                           (u64)(unsigned)__builtin_amdgcn_readlane((int)row_lo, i);
+            a &= ~ri;
+            todo = a & ~((2ull << i) - 1ull);
+        }
+        int ktot = __builtin_amdgcn_readfirstlane(S.ktot), nk = __popcll(a);
+        bool stop = false;
+        if (top_k > 0 && ktot + nk >= top_k) {                   // only the segment's first top_k kept boxes matter
+            int excess = ktot + nk - top_k;
+            while (excess-- > 0) a &= ~(1ull << (63 - __builtin_clzll(a)));
+            nk = top_k - ktot;
+            stop = true;
+        }
+        const int slot = t & (RT - 1);
+        if ((a >> lane) & 1ull) {
+            const int pos = slot * 64 + vx_mbcnt(a);
+            rbox[pos] = bxn;
+            rar[pos] = arn;
+        }
+        if (lane < VX_ASYNC_TRIP) {                              // pad the slot to whole trips with a box that meets nothing
+            const int pos = nk + lane;
+            if (pos < ((nk + VX_ASYNC_TRIP - 1) & ~(VX_ASYNC_TRIP - 1))) {
+                const vx_f4 far = {1e30f, 1e30f, 1e30f, 1e30f};
+                rbox[slot * 64 + pos] = far;
+                rar[slot * 64 + pos] = 0.0f;
+            }
+        }
+        if (lane == 0) { S.alive[t] = a; S.wild[t] = (a & untn) != 0ull; S.ktot = ktot + nk; S.ndone = t + 1; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            __hip_atomic_store(&S.ready, (stop || t + 1 >= NT) ? NT : t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // diagnostics (dbg != nullptr only while profiling): cycles this wave spent waiting / applying / on the chain
+    u64 c_wait = 0, c_apply = 0, c_chain = 0, c_rows = 0, c0 = dbg ? clock64() : 0, cs = c0;
+#define VX_LAP(acc) do { if (dbg) { u64 now_ = clock64(); acc += now_ - cs; cs = now_; } } while (0)
+    make_rows();
+    if (w == 0) { resolve(0, vx_uniform64(S.alive[0])); nxt += W; make_rows(); }
+    VX_LAP(c_rows);
+    for (int t = 0; t + 1 < NT; ++t) {
+        if (nxt >= NT) break;                                    // no tile left to resolve or to apply to (nxt > t always)
+        int r;
+        while ((r = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&S.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) <= t)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        VX_LAP(c_wait);
+        if (r >= NT) break;                                      // every tile is final (last one resolved, or the top_k stop)
+        const int slot = t & (RT - 1);
+        const int kc = __builtin_amdgcn_readfirstlane(__popcll(S.alive[t]));
+        const bool all_slow = all_slow0 || __builtin_amdgcn_readfirstlane((int)S.wild[t]) != 0;
+        const vx_f4 *kb = rbox + slot * 64;
+        const float *kar = rar + slot * 64;
+        int u = nxt;                                             // this wave's first tile behind t
+        if (t + 1 == nxt) {                                      // this wave owns tile t+1: the chain's next link
+            __builtin_amdgcn_s_setprio(3);
+            u64 a = vx_uniform64(S.alive[nxt]);
+            tests += (unsigned long long)kc * __popcll(a);
+            if (kc > 0 && a) vx_async_apply<1>(kb, kar, kc, all_slow, &bxn, &arn, &a, &untn, T);
+            resolve(nxt, a);
+            __builtin_amdgcn_s_setprio(0);
+            VX_LAP(c_chain);
+            nxt += W;
+            u = nxt;
+        }
+        if (kc > 0) {
+            // own tiles behind the chain, two per trip; the next pair's boxes are in flight meanwhile
+            vx_f4 B[2], Bn[2];
+            B[0] = load_tile(u); B[1] = load_tile(u + W);
+            for (; u < NT; u += 2 * W) {
+                // the top_k stop ends the sweep for everybody: the far tiles are not needed any more
+                if (top_k > 0 && __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(&S.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NT) break;
+                Bn[0] = load_tile(u + 2 * W); Bn[1] = load_tile(u + 3 * W);
+                u64 al[2], un[2];
+                al[0] = vx_uniform64(S.alive[u]);
+                al[1] = u + W < NT ? vx_uniform64(S.alive[u + W]) : 0ull;
+                if (al[0] | al[1]) {
+                    float ar[2];
+                    ar[0] = (B[0].z - B[0].x) * (B[0].w - B[0].y);
+                    ar[1] = (B[1].z - B[1].x) * (B[1].w - B[1].y);
+                    un[0] = __ballot(!vx_tame(B[0], ar[0])) & al[0];
+                    un[1] = __ballot(!vx_tame(B[1], ar[1])) & al[1];
+                    tests += (unsigned long long)kc * (__popcll(al[0]) + __popcll(al[1]));
+                    const u64 b0 = al[0], b1 = al[1];
+                    if (al[1] == 0ull) vx_async_apply<1>(kb, kar, kc, all_slow, B, ar, al, un, T);
+                    else if (al[0] == 0ull) vx_async_apply<1>(kb, kar, kc, all_slow, B + 1, ar + 1, al + 1, un + 1, T);
+                    else vx_async_apply<2>(kb, kar, kc, all_slow, B, ar, al, un, T);
+                    if (lane == 0) {
+                        if (al[0] != b0) S.alive[u] = al[0];
+                        if (al[1] != b1) S.alive[u + W] = al[1];
+                    }
+                }
+                B[0] = Bn[0]; B[1] = Bn[1];
+            }
+        }
+        VX_LAP(c_apply);
+        if (t + 1 + W == nxt) { make_rows(); VX_LAP(c_rows); }   // just resolved a tile: rows of the next own one
+    }
+    if (iou_count && lane == 0 && tests) atomicAdd(iou_count, tests);        // wave-uniform count of useful lane-tests
+    if (dbg && lane == 0 && w < 16) {
+        u64 *d = dbg + w * 8;
+        d[0] = c_wait; d[1] = c_apply; d[2] = c_chain; d[3] = c_rows; d[4] = clock64() - c0; d[5] = tests;
+    }
+#undef VX_LAP
+    __syncthreads();
+}
+
+// kept masks of vx_sweep_async -> keys2 (keys = the segment's sorted key1s in global memory)
+template <int MAXTILES>
+__device__ __forceinline__ void vx_async_emit(const vx_async_smem_t<MAXTILES> &S, const u64 *__restrict__ keys,
+                                              u64 *__restrict__ keys2, int *count2) {
+    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ND = S.ndone;
+    for (int u = wave; u < ND; u += nw) {
+        const u64 m = S.alive[u];
+        const bool mine = (m >> lane) & 1ull;
+        const u64 key = mine ? keys[u * 64 + lane] : 0ull;
         vx_emit_kept(m, mine, key, keys2, count2);
     }
     __syncthreads();
@@ -702,8 +849,10 @@ __device__ __forceinline__ void vx_sweep_block(SM &S, const vx_f4 *__restrict__ 
 __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
                                                       const float *__restrict__ sarea,
                                                       const int *__restrict__ counts, vx_nms_params p,
-                                                      u64 *__restrict__ keys2, int *__restrict__ count2) {
-    __shared__ vx_sweep_smem S;
+                                                      u64 *__restrict__ keys2, int *__restrict__ count2,
+                                                      unsigned long long *iou_count) {
+    __shared__ vx_async_smem_big S;
+    __shared__ __attribute__((aligned(16))) unsigned char s_ring[(2 * 16 * 64 + 8) * 20];      // vx_async_ring_bytes(16 waves)
     __shared__ int s_big[VX_SWEEP_MAXBIG][2];
     __shared__ int s_nbig;
     const int b = blockIdx.y;
@@ -740,7 +889,10 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
     __syncthreads();
     // phase B: large segments, whole workgroup each
     const int nbig = s_nbig;
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, k1, s_big[q][0], s_big[q][1], T, k2, c2, p.top_k);
+    for (int q = 0; q < nbig; ++q) {
+        vx_sweep_async(S, s_ring, sb + s_big[q][0], s_big[q][1], T, p.top_k, iou_count);
+        vx_async_emit(S, k1 + s_big[q][0], k2, c2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -772,6 +924,7 @@ struct vx_part_args {
     vx_f4 *sbox;
     float *sarea;
     int *count2, *status;
+    unsigned long long *iou_count;   // optional: useful lane-level IoU tests executed (measurement only)
 };
 
 __device__ __forceinline__ int vx_part_class(long long c, int n_classes, bool &bad) {
@@ -860,10 +1013,10 @@ __global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
     }
 }
 
-template <int LDS_KEYS>
-__global__ __launch_bounds__(512) void vx_k_part_sweep(vx_part_args a) {
+template <int LDS_KEYS, int THREADS>
+__global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
-    __shared__ vx_sweep_smem_image S;
+    __shared__ vx_async_smem A;
     const int b = blockIdx.y, c = blockIdx.x;
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
     const int lo = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
@@ -874,31 +1027,36 @@ __global__ __launch_bounds__(512) void vx_k_part_sweep(vx_part_args a) {
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
     const int nt = blockDim.x;
     const int npad = vx_next_pow2(len);
-    const u64 *kin = a.keys1 + ob + lo;
-    for (int i = threadIdx.x; i < npad; i += nt) sk[i] = i < len ? kin[i] : VX_KEY_SENTINEL;
+    u64 *kseg = a.keys1 + ob + lo;
+    for (int i = threadIdx.x; i < npad; i += nt) sk[i] = i < len ? kseg[i] : VX_KEY_SENTINEL;
     __syncthreads();
     vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
-    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
+    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area; the sorted keys go
+    // back to the segment's place in global memory (the LDS is reused for the boxes of a large segment)
     vx_f4 *sb = a.sbox + ob + lo;
     float *sa = a.sarea + ob + lo;
     const float off = (float)(c * (VX_MAX_COORDINATE + 1));
+    const bool big = len > 64 * VX_SWEEP_WT;
     bool oob = false;
     for (int i = threadIdx.x; i < len; i += nt) {
-        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(sk[i])) * 4);
+        const u64 key = sk[i];
+        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
         oob |= !vx_box_in_range(bx);
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         sb[i] = bx;
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
+        if (big) kseg[i] = key;
     }
     if (__ballot(oob) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_RANGE);
     __syncthreads();
     const vx_thr T = vx_make_thr(p.thr);
     u64 *k2 = a.keys2 + ob;
     int *c2 = a.count2 + b;
-    if (len <= 64 * VX_SWEEP_WT) {
+    if (!big) {
         if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2);
     } else {
-        vx_sweep_block(S, sb, sa, sk, 0, len, T, k2, c2, p.top_k);
+        vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
+        vx_async_emit(A, kseg, k2, c2);
     }
 }
 
@@ -1004,7 +1162,9 @@ struct vx_image_args {
     const int *counts;
     vx_f4 *sbox;
     float *sarea;
+    u64 *keys1;       // sorted key1s of the image (read back when kept boxes are emitted: the LDS copy is overlaid)
     u64 *keys2;
+    unsigned long long *iou_count;   // optional: useful lane-level IoU tests executed (measurement only)
     long long *keep_idx;
     float *out_det;
     int *keep_counts, *status;
@@ -1091,7 +1251,7 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
 
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
-    __shared__ vx_sweep_smem_image S;
+    __shared__ vx_async_smem A;
     __shared__ int s_big[VX_SWEEP_MAXBIG][2];
     __shared__ int s_nbig, s_count2, s_nseg;
     __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
@@ -1118,7 +1278,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     const int npad = vx_next_pow2(n);
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
-#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * 8 + (k)] = clock64(); } while (0)
+#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + (k)] = clock64(); } while (0)
     VX_STAMP(0);
     bool bad = false;
     for (int i = threadIdx.x; i < npad; i += nt) {
@@ -1140,9 +1300,11 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
     vx_f4 *sb = a.sbox + ob;
     float *sa = a.sarea + ob;
+    u64 *kg = a.keys1 + ob;
     bool oob = false;
     for (int i = threadIdx.x; i < n; i += nt) {
         u64 key = sk[i];
+        kg[i] = key;
         float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
         vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
         oob |= !vx_box_in_range(bx);
@@ -1202,8 +1364,14 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     __syncthreads();
     VX_STAMP(4);
+    // large segments, the whole workgroup each (chain sweep; its kept-box ring takes the keys' LDS -- the sorted keys
+    // live on in kg)
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
-    for (int q = 0; q < nbig; ++q) vx_sweep_block(S, sb, sa, sk, s_big[q][0], s_big[q][1], T, k2, &s_count2, p.top_k);
+    for (int q = 0; q < nbig; ++q) {
+        const int lo = s_big[q][0], len = s_big[q][1];
+        vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
+        vx_async_emit(A, kg + lo, k2, &s_count2);
+    }
     __syncthreads();
     VX_STAMP(5);
     // kept keys back into global score order, then the outputs
@@ -1251,7 +1419,7 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.sarea = (float *)(p + off); off += vx_align256n(n * sizeof(float));
     w.keys2 = (u64 *)(p + off); off += vx_align256n(n * sizeof(u64));
     w.count2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
-    w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * 8 * sizeof(u64));   // per-image phase clocks (diagnostics)
+    w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * VX_STAMP_WORDS * sizeof(u64));   // per-image phase clocks (diagnostics)
     w.seg = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
     w.sel = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.part_hist = (int *)(p + off); off += (size_t)B * VX_PART_MAX_CLASSES * sizeof(int);
@@ -1343,10 +1511,14 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg;   // phase clocks only while profiling
         a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only;
+        a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
         int threads = lds_keys >= 1024 ? 1024 : 256;
+        // the same LDS holds the sort keys and later the kept-box ring of the column-owner sweep
+        size_t lds = (size_t)lds_keys * sizeof(u64);
+        if (lds < vx_async_ring_bytes(threads / 64)) lds = vx_async_ring_bytes(threads / 64);
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
-        hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), (size_t)lds_keys * sizeof(u64), st, a);
+        hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), lds, st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
         if (all_fit || small_only) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
@@ -1358,7 +1530,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
         if (!part_attr_set[dev]) {
-            if (hipFuncSetAttribute((const void *)vx_k_part_sweep<VX_SORT_CHMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void *)vx_k_part_sweep<VX_SORT_CHMAX, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
                 return VX_ERR_LAUNCH;
             part_attr_set[dev] = true;
@@ -1367,6 +1539,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.cls = (const long long *)d_cls; a.sel = w.sel;
         a.hist = w.part_hist; a.cursor = w.part_cursor; a.segstart = w.part_segstart; a.sel2 = w.sel2;
         a.keys1 = w.keys1; a.keys2 = w.keys2; a.sbox = w.sbox; a.sarea = w.sarea; a.count2 = w.count2; a.status = d_status;
+        a.iou_count = vx_iou_counter();
         if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
             return VX_ERR_LAUNCH;
         dim3 tiles((capacity + VX_PART_TILE - 1) / VX_PART_TILE, B);
@@ -1375,8 +1548,9 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         hipLaunchKernelGGL(vx_k_part_scatter, tiles, dim3(1024), 0, st, a);
         vx_prof_end(VX_PROF_NMS_KEYS, st);
         vx_prof_begin(VX_PROF_SWEEP, st);
-        hipLaunchKernelGGL(vx_k_part_sweep<VX_PART_SMALL>, dim3(n_classes, B), dim3(512), VX_PART_SMALL * sizeof(u64), st, a);
-        hipLaunchKernelGGL(vx_k_part_sweep<VX_SORT_CHMAX>, dim3(n_classes, B), dim3(512), VX_SORT_CHMAX * sizeof(u64), st, a);
+        // dynamic LDS: the segment's keys while sorting, then the kept-box ring of the column-owner sweep (20 KiB at 8 waves)
+        hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), vx_async_ring_bytes(8), st, a);
+        hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(n_classes, B), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
         vx_prof_end(VX_PROF_SWEEP, st);
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
     }
@@ -1404,7 +1578,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     if (X < 1) X = 1;
     vx_prof_begin(VX_PROF_SWEEP, st);
     hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
-                       w.count2);
+                       w.count2, vx_iou_counter());
     vx_prof_end(VX_PROF_SWEEP, st);
     vx_prof_begin(VX_PROF_SORT2, st);
     if (top_k > 0 && top_k <= VX_TOPK_MAX)             // only the first top_k keys are needed: select, then sort those

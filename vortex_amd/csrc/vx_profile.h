@@ -16,3 +16,6 @@ void vx_prof_end_impl(int slot, hipStream_t st);
 
 static inline void vx_prof_begin(int slot, hipStream_t st) { if (vx_prof_on) vx_prof_begin_impl(slot, st); }
 static inline void vx_prof_end(int slot, hipStream_t st) { if (vx_prof_on) vx_prof_end_impl(slot, st); }
+
+// device counter of useful lane-level IoU tests (NMS sweeps add to it) or nullptr: vx_profile_set_iou_counter
+unsigned long long *vx_iou_counter();
