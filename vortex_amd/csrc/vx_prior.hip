@@ -13,8 +13,18 @@ struct vx_prior_params {
     int use_thr;
 };
 
-// One workgroup = 256 consecutive rows.  The tile (256*NCOL contiguous floats) is streamed into LDS
-// with coalesced loads, rows padded to an odd stride so the row-per-lane pass is conflict-free.
+// One workgroup = VX_PRIOR_TPW consecutive tiles of 256 rows of one image.  A tile (256*NCOL contiguous floats) is
+// streamed with coalesced 16-B non-temporal loads into registers while the previous tile is decoded out of LDS
+// (software pipeline: the loads of tile j+1 are in flight during the row pass of tile j), then written to LDS:
+//   LAYOUT 1 (NCOL odd, e.g. FPN-SSD 25): the LDS image is the flat tile (one ds_write_b128 per load); an odd row
+//            stride makes the row-per-lane pass conflict-free as it is
+//   LAYOUT 0 (any NCOL): rows padded to the odd stride NCP = NCOL | 1, four ds_write_b32 per load with the (row, col)
+//            of each element advanced incrementally (no per-element division); when NCOL % 4 == 0 (RetinaFace 16) a
+//            load never straddles a row and the carry disappears
+#define VX_PRIOR_TPW 4
+// MAXQ = 16-B loads per thread and tile = ceil(NCOL / 4): 4 (NCOL <= 16), 8 (<= 32) or 16 (<= 63)
+
+template <int LAYOUT, int MAXQ>
 __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict__ in,
                                                          const vx_f4 *__restrict__ priors,
                                                          vx_rec *__restrict__ stage, float *__restrict__ stage_lmk,
@@ -22,103 +32,156 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict
                                                          vx_prior_params p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ int s_wcount[4];
-    const int t = blockIdx.x % p.tiles_per_img, b = blockIdx.x / p.tiles_per_img;
-    const int row0 = t * 256;
-    const int nrow = min(256, p.P - row0);
-    const int NCOL = p.NCOL, NCP = p.NCP;
-    const float *g = in + ((long long)b * p.P + row0) * NCOL;
-    const int n = nrow * NCOL;
+    __shared__ int2 s_list[256];
+    float *lmk_lds = tile + 256 * (LAYOUT == 1 ? p.NCOL : p.NCP);     // [256][2L] behind the tile
+    typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int groups = (p.tiles_per_img + VX_PRIOR_TPW - 1) / VX_PRIOR_TPW;
+    const int grp = blockIdx.x % groups, b = blockIdx.x / groups;
+    const int t0 = grp * VX_PRIOR_TPW, t1 = min(t0 + VX_PRIOR_TPW, p.tiles_per_img);
+    const int NCOL = p.NCOL, NCP = LAYOUT == 1 ? NCOL : p.NCP;
+    const int lane = vx_lane(), wave = threadIdx.x >> 6;
+    const int r = threadIdx.x;
+    const bool quad_rows = (NCOL & 3) == 0;
     bool nan = false;
-    {
-        // 16-B flat loads of the contiguous tile (dword alignment suffices); float4 f = threadIdx.x + 256*k covers
-        // elements 4f..4f+3 -> (row, col) advanced incrementally, rows padded to the odd stride NCP in LDS
-        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
-        const int n4 = n >> 2;
+    v4u q[MAXQ];
+    // loads of tile t into registers (whole 16-B groups; the < 4 leftover floats of a partial last tile are read in the store step)
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        const int row0 = t * 256;
+        const int n4 = (min(256, p.P - row0) * NCOL) >> 2;
+        const float *g = in + ((long long)b * p.P + row0) * NCOL;
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int f = threadIdx.x + 256 * k;
+            if (f < n4) q[k] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(g + 4 * f));
+        }
+    };
+    auto store_tile = [&](int t) __attribute__((always_inline)) {
+        const int row0 = t * 256;
+        const int n = min(256, p.P - row0) * NCOL, n4 = n >> 2;
         int e0 = threadIdx.x * 4;
         int row = e0 / NCOL, col = e0 - row * NCOL;
         const int drow = 1024 / NCOL, dcol = 1024 - drow * NCOL;
-        for (int f = threadIdx.x; f < n4; f += 256) {
-            v4u q = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(g + 4 * f));
-            float v[4] = {q.x, q.y, q.z, q.w};
-            int rr = row, cc = col;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                nan |= (v[j] != v[j]);
-                tile[rr * NCP + cc] = v[j];
-                if (++cc == NCOL) { cc = 0; ++rr; }
+        for (int k = 0; k < MAXQ; ++k) {
+            const int f = threadIdx.x + 256 * k;
+            if (f < n4) {
+                const v4u v = q[k];
+                nan |= __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);      // v_cmp_u_f32: 2 per load
+                if (LAYOUT == 1) {
+                    *reinterpret_cast<vx_v4 *>(tile + 4 * f) = vx_v4{v.x, v.y, v.z, v.w};
+                } else if (quad_rows) {
+                    float *d = tile + row * NCP + col;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    int rr = row, cc = col;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tile[rr * NCP + cc] = vv[j];
+                        if (++cc == NCOL) { cc = 0; ++rr; }
+                    }
+                }
             }
             row += drow; col += dcol;
             if (col >= NCOL) { col -= NCOL; ++row; }
         }
+        const float *g = in + ((long long)b * p.P + row0) * NCOL;
         for (int e = n4 * 4 + threadIdx.x; e < n; e += 256) {       // < 4 leftover floats of a partial last tile
             float v = g[e];
             nan |= (v != v);
             int rr = e / NCOL;
             tile[rr * NCP + (e - rr * NCOL)] = v;
         }
-    }
-    if (__ballot(nan) != 0 && vx_lane() == 0) atomicOr(status, VX_STATUS_NAN);
-    __syncthreads();
-    const int r = threadIdx.x;
-    const int lane = vx_lane(), wave = threadIdx.x >> 6;
-    bool pass = false;
-    float conf = 0.f;
-    int ci = 0;
-    const float *row = tile + r * NCP;
-    if (r < nrow) {
-        float *lg = tile + r * NCP + 4 + 2 * p.L;
-        float m = lg[0];
-        for (int k = 1; k < p.NC; ++k) m = lg[k] > m ? lg[k] : m;
-        // one exp per logit: e_k replaces the logit in LDS, sum in class order, (max e, first index) on the way
-        float e0 = vx_exp(lg[0] - m);
-        float sum = 0.f + e0, emax = -1.f;
-        int kmax = 1;
-        for (int k = 1; k < p.NC; ++k) {
-            float e = vx_exp(lg[k] - m);
-            lg[k] = e;
-            sum = sum + e;
-            if (e > emax) { emax = e; kmax = k; }
-        }
-        // max_k fl(e_k/sum) == fl(max_k e_k / sum): a correctly rounded division is monotonic in its numerator
-        conf = emax / sum;
-        ci = kmax - 1;
-        // "first index of the maximum probability": an earlier class whose e is within an ulp or two of emax can
-        // round to the same quotient -- the only case that needs another division
-        const float near = emax * 0.999999f;
-        for (int k = 1; k < kmax; ++k) {
-            float e = lg[k];
-            if (e >= near && e / sum == conf) { ci = k - 1; break; }
-        }
-        pass = p.use_thr ? (conf > p.thr) : true;
-    }
-    u64 mk = __ballot(pass);
-    if (lane == 0) s_wcount[wave] = __popcll(mk);
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += s_wcount[w];
-    if (pass) {
-        int pos = base + vx_mbcnt(mk);
-        vx_f4 pr = priors[row0 + r];
-        float cx = pr.x + (row[0] * p.v0) * pr.z;
-        float cy = pr.y + (row[1] * p.v0) * pr.w;
-        float w = pr.z * vx_exp(row[2] * p.v1);
-        float h = pr.w * vx_exp(row[3] * p.v1);
-        float hw = w / 2.0f, hh = h / 2.0f;
-        vx_rec rec;
-        rec.a.x = cx - hw; rec.a.y = cy - hh; rec.a.z = cx + hw; rec.a.w = cy + hh;
-        rec.b.x = conf; rec.b.y = conf; rec.b.z = __int_as_float(ci); rec.b.w = __int_as_float(row0 + r);
-        long long o = (long long)b * p.P + row0 + pos;
-        stage[o] = rec;
-        if (p.L > 0) {
-            float *lm = stage_lmk + o * (2 * p.L);
-            for (int q = 0; q < p.L; ++q) {
-                lm[2 * q] = pr.x + (row[4 + 2 * q] * p.v0) * pr.z;
-                lm[2 * q + 1] = pr.y + (row[5 + 2 * q] * p.v0) * pr.w;
+    };
+    load_tile(t0);
+    for (int t = t0; t < t1; ++t) {
+        const int row0 = t * 256;
+        const int nrow = min(256, p.P - row0);
+        store_tile(t);
+        __syncthreads();
+        if (t + 1 < t1) load_tile(t + 1);                           // in flight during the row pass below
+        bool pass = false;
+        float conf = 0.f;
+        int ci = 0;
+        const float *row = tile + r * NCP;
+        if (r < nrow) {
+            const float *lg = row + 4 + 2 * p.L;
+            float m = lg[0];
+            for (int k = 1; k < p.NC; ++k) m = lg[k] > m ? lg[k] : m;
+            // one exp per logit, sum in class order, (max e, first index) on the way; `before` = the largest e in
+            // front of that index
+            float e0 = vx_exp(lg[0] - m);
+            float sum = 0.f + e0, emax = -1.f, before = -1.f;
+            int kmax = 1;
+            for (int k = 1; k < p.NC; ++k) {
+                float e = vx_exp(lg[k] - m);
+                sum = sum + e;
+                if (e > emax) { before = emax; emax = e; kmax = k; }
+            }
+            // max_k fl(e_k/sum) == fl(max_k e_k / sum): a correctly rounded division is monotonic in its numerator
+            conf = emax / sum;
+            ci = kmax - 1;
+            pass = p.use_thr ? (conf > p.thr) : true;
+            // "first index of the maximum probability": an earlier class whose e is within an ulp or two of emax can
+            // round to the same quotient -- the only case that needs more divisions (about one row in a million)
+            if (pass && before >= emax * 0.999999f) {
+                for (int k = 1; k < kmax; ++k) {
+                    float e = vx_exp(lg[k] - m);
+                    if (e / sum == conf) { ci = k - 1; break; }
+                }
             }
         }
+        u64 mk = __ballot(pass);
+        if (lane == 0) s_wcount[wave] = __popcll(mk);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wcount[w];
+        // survivors are decoded densely: each passing row leaves (row, class, confidence) in a list at its compacted
+        // position; then thread i decodes survivor i -- with a few survivors per wave (5.8 of 64 on the RetinaFace
+        // batch) the decode arithmetic and its stores run once per 64 survivors instead of once per wave
+        if (pass) {
+            const int pos = base + vx_mbcnt(mk);
+            s_list[pos] = make_int2(r | (ci << 8), __float_as_int(conf));
+        }
+        const int total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        __syncthreads();
+        if (r < total) {
+            const int2 e = s_list[r];
+            const int rr = e.x & 255, cls = e.x >> 8;
+            const float cf = __int_as_float(e.y);
+            const float *srow = tile + rr * NCP;
+            vx_f4 pr = priors[row0 + rr];
+            float cx = pr.x + (srow[0] * p.v0) * pr.z;
+            float cy = pr.y + (srow[1] * p.v0) * pr.w;
+            float w = pr.z * vx_exp(srow[2] * p.v1);
+            float h = pr.w * vx_exp(srow[3] * p.v1);
+            float hw = w / 2.0f, hh = h / 2.0f;
+            vx_rec rec;
+            rec.a.x = cx - hw; rec.a.y = cy - hh; rec.a.z = cx + hw; rec.a.w = cy + hh;
+            rec.b.x = cf; rec.b.y = cf; rec.b.z = __int_as_float(cls); rec.b.w = __int_as_float(row0 + rr);
+            long long o = (long long)b * p.P + row0 + r;
+            stage[o] = rec;
+            if (p.L > 0) {                                          // landmarks: into the row's own LDS slot, copied out below
+                float lmv[2];
+                float *ld = lmk_lds + r * (2 * p.L);
+                for (int qq = 0; qq < p.L; ++qq) {
+                    lmv[0] = pr.x + (srow[4 + 2 * qq] * p.v0) * pr.z;
+                    lmv[1] = pr.y + (srow[5 + 2 * qq] * p.v0) * pr.w;
+                    ld[2 * qq] = lmv[0]; ld[2 * qq + 1] = lmv[1];
+                }
+            }
+        }
+        if (threadIdx.x == 0) tile_counts[(long long)b * p.tiles_per_img + t] = total;
+        if (p.L > 0) {
+            // the tile's survivors own one contiguous block of stage_lmk: consecutive lanes write consecutive floats
+            __syncthreads();
+            float *lg_out = stage_lmk + ((long long)b * p.P + row0) * (2 * p.L);
+            const int nl = total * 2 * p.L;
+            for (int i = threadIdx.x; i < nl; i += 256) lg_out[i] = lmk_lds[i];
+        }
+        __syncthreads();                                            // the tile, the lists and s_wcount are rewritten by the next trip
     }
-    if (threadIdx.x == 0)
-        tile_counts[(long long)b * p.tiles_per_img + t] = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
 }
 
 static inline size_t vx_align256p(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -157,10 +220,18 @@ extern "C" int vx_prior_decode(const float *d_in, const float *d_priors, int B, 
     p.tiles_per_img = tiles; p.v0 = variance0; p.v1 = variance1; p.thr = score_threshold;
     p.use_thr = use_threshold ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = (size_t)256 * p.NCP * sizeof(float);
+    size_t lds = (size_t)256 * (p.NCP + 2 * n_landmarks) * sizeof(float);
+    const int groups = (tiles + VX_PRIOR_TPW - 1) / VX_PRIOR_TPW;
     vx_prof_begin(VX_PROF_PRIOR, st);
-    hipLaunchKernelGGL(vx_k_prior_decode, dim3((unsigned)(B * tiles)), dim3(256), lds, st, d_in,
-                       (const vx_f4 *)d_priors, stage, stage_lmk, tile_counts, d_status, p);
+#define VX_PRIOR_LAUNCH(LAYOUT, MAXQ)                                                                                  \
+    hipLaunchKernelGGL((vx_k_prior_decode<LAYOUT, MAXQ>), dim3((unsigned)(B * groups)), dim3(256), lds, st, d_in,             \
+                       (const vx_f4 *)d_priors, stage, stage_lmk, tile_counts, d_status, p)
+    if (NCOL & 1) {
+        if (NCOL <= 16) VX_PRIOR_LAUNCH(1, 4); else if (NCOL <= 32) VX_PRIOR_LAUNCH(1, 8); else VX_PRIOR_LAUNCH(1, 16);
+    } else {
+        if (NCOL <= 16) VX_PRIOR_LAUNCH(0, 4); else if (NCOL <= 32) VX_PRIOR_LAUNCH(0, 8); else VX_PRIOR_LAUNCH(0, 16);
+    }
+#undef VX_PRIOR_LAUNCH
     vx_prof_end(VX_PROF_PRIOR, st);
     vx_finish_params f;
     f.R = P; f.tiles_per_img = tiles; f.D = 6 + 2 * n_landmarks; f.L = n_landmarks; f.uniform_tile_rows = 256;
