@@ -64,7 +64,8 @@ def test_normalize_vs_oracle_shapes(shape):
 
 
 @pytest.mark.parametrize("letterbox", [False, True])
-@pytest.mark.parametrize("src,dst", [((72, 128), (64, 64)), ((33, 21), (48, 40)), ((50, 50), (20, 30))])
+@pytest.mark.parametrize("src,dst", [((72, 128), (64, 64)), ((33, 21), (48, 40)), ((50, 50), (20, 30)),
+                                     ((720, 1280), (416, 416)), ((100, 37), (64, 64)), ((64, 3), (32, 8))])
 def test_resize_normalize_vs_oracle(src, dst, letterbox):
     rng = np.random.default_rng(5)
     imgs = rng.integers(0, 256, (2, src[0], src[1], 3), dtype=np.uint8)

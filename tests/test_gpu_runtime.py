@@ -34,7 +34,10 @@ def _same_results(got, exp):
 
 
 @pytest.mark.parametrize("src,dst", [((720, 1280), (416, 416)), ((37, 53), (64, 48)), ((100, 100), (50, 50)),
-                                     ((30, 40), (90, 120)), ((416, 416), (416, 416)), ((5, 3), (7, 2))])
+                                     ((30, 40), (90, 120)), ((416, 416), (416, 416)), ((5, 3), (7, 2)),
+                                     # the streaming kernel's corners: 3-pixel-wide source (every window clamped), a
+                                     # letterbox offset that is no multiple of 4, one source row, strong up-scaling in x
+                                     ((64, 3), (32, 8)), ((100, 37), (64, 64)), ((1, 200), (16, 400)), ((9, 7), (40, 2048))])
 @pytest.mark.parametrize("letterbox", [False, True])
 def test_resize_u8_vs_oracle(src, dst, letterbox):
     rng = np.random.default_rng(src[0] * 31 + dst[1])

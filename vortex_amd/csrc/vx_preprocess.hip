@@ -224,6 +224,123 @@ __global__ __launch_bounds__(256) void vx_k_resize_normalize(const uint8_t *__re
     }
 }
 
+// Streaming form of the two kernels above for Wd % 4 == 0 and a source of at least 3 x 1 pixels: a workgroup owns
+// VX_RS_ROWS output rows of one image.  It first builds, in LDS, the x tap table of the whole output row (one entry
+// per output column: byte offset of an 8-byte window holding both taps, the window's shift, the two 11-bit weights)
+// and the y taps of its rows -- the double-precision coordinate of OpenCV's scheme is evaluated once per table entry,
+// not per pixel -- then every thread produces 4 consecutive output pixels: per pixel two unaligned 8-byte loads (the
+// tap pair of the upper and of the lower source row; neighbouring lanes share cache lines), integer blends, and the
+// store: three 16-byte non-temporal plane stores (normalise: table lookup in LDS) or 12 contiguous bytes (u8 output).
+#define VX_RS_ROWS 8
+#define VX_RS_MAXW 2048                    // output width the LDS tap table holds (8 B per column: 16 KiB)
+
+struct vx_xtap { int off; unsigned sw; };          // sw = shift (0 / 8 / 16 bits) << 24 | w1 << 12 | w0
+
+__device__ __forceinline__ unsigned long long vx_load8(const uint8_t *p) {
+    typedef unsigned long long u64u __attribute__((aligned(1)));
+    return *reinterpret_cast<const u64u *>(p);
+}
+
+template <bool NORM>
+__global__ __launch_bounds__(256) void vx_k_resize_fast(const uint8_t *__restrict__ src, void *__restrict__ dstv,
+                                                        vx_resize_params r, vx_norm_params p) {
+    __shared__ float lut[NORM ? 768 : 1];
+    __shared__ vx_xtap xt[VX_RS_MAXW];
+    __shared__ int yt[VX_RS_ROWS][4];               // y0 row, y1 row, b0, b1 (row < 0: padding row)
+    const int b = blockIdx.y, yb = blockIdx.x * VX_RS_ROWS;
+    if (NORM) vx_build_lut(lut, p);
+    for (int x = threadIdx.x; x < r.Wd; x += 256) {
+        vx_xtap t;
+        const int xx = x - r.left;
+        if (xx < 0 || xx >= r.nw) { t.off = -1; t.sw = 0u; }
+        else {
+            int x0, x1, a0, a1;
+            vx_tap(xx, r.nw, r.Ws, x0, x1, a0, a1);
+            // the pair (xb, xb+1) inside the row; at the right border (x1 == x0) the tap is the pair's second pixel
+            const int xb = min(x0, r.Ws - 2);
+            int w0 = a0, w1 = a1;
+            if (x0 != xb) { w0 = 0; w1 = a0; }
+            // an 8-byte window that holds the pair's 6 bytes and stays inside the row: it starts at the pair, or (for the
+            // row's last pair) 2 bytes earlier
+            const int ob = min(xb * 3, r.Ws * 3 - 8);
+            t.off = ob;
+            t.sw = ((unsigned)((xb * 3 - ob) * 8) << 24) | ((unsigned)w1 << 12) | (unsigned)w0;
+        }
+        xt[x] = t;
+    }
+    if (threadIdx.x < VX_RS_ROWS) {
+        const int y = yb + threadIdx.x, yy = y - r.top;
+        int y0 = -1, y1 = -1, b0 = 0, b1 = 0;
+        if (y < r.Hd && yy >= 0 && yy < r.nh) vx_tap(yy, r.nh, r.Hs, y0, y1, b0, b1);
+        yt[threadIdx.x][0] = y0; yt[threadIdx.x][1] = y1; yt[threadIdx.x][2] = b0; yt[threadIdx.x][3] = b1;
+    }
+    __syncthreads();
+    const int QW = r.Wd >> 2;                        // 4-pixel groups per row
+    const int nq = min(VX_RS_ROWS, r.Hd - yb) * QW;
+    const float inv_qw = 1.0f / (float)QW;
+    const uint8_t *simg = src + (long long)b * r.Hs * r.Ws * 3;
+    const long long HWd = (long long)r.Hd * r.Wd;
+    const int s0 = p.flip ? 2 : 0, s2 = p.flip ? 0 : 2;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        int ry = (int)(((float)q + 0.5f) * inv_qw);
+        int xq = q - ry * QW;
+        if (xq < 0) { --ry; xq += QW; } else if (xq >= QW) { ++ry; xq -= QW; }
+        const int y0 = yt[ry][0], y1 = yt[ry][1], b0 = yt[ry][2], b1 = yt[ry][3];
+        int v[4][3];
+        if (y0 < 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k][0] = v[k][1] = v[k][2] = r.pad;
+        } else {
+            const uint8_t *r0 = simg + (long long)y0 * r.Ws * 3, *r1 = simg + (long long)y1 * r.Ws * 3;
+            unsigned long long u0[4], u1[4];
+            vx_xtap t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] = xt[xq * 4 + k];
+                const int o = t[k].off < 0 ? 0 : t[k].off;
+                u0[k] = vx_load8(r0 + o);
+                u1[k] = vx_load8(r1 + o);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned sh = t[k].sw >> 24;
+                const int w0 = (int)(t[k].sw & 0xFFFu), w1 = (int)((t[k].sw >> 12) & 0xFFFu);
+                const unsigned long long p0 = u0[k] >> sh, p1 = u1[k] >> sh;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int h0 = (int)((p0 >> (8 * c)) & 0xFFu) * w0 + (int)((p0 >> (8 * c + 24)) & 0xFFu) * w1;
+                    const int h1 = (int)((p1 >> (8 * c)) & 0xFFu) * w0 + (int)((p1 >> (8 * c + 24)) & 0xFFu) * w1;
+                    const int val = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    v[k][c] = t[k].off < 0 ? r.pad : min(max(val, 0), 255);
+                }
+            }
+        }
+        const int y = yb + ry, x = xq * 4;
+        if (NORM) {
+            float *d = reinterpret_cast<float *>(dstv) + (long long)b * 3 * HWd + (long long)y * r.Wd + x;
+            vx_v4 o0, o1, o2;
+            o0.x = lut[v[0][s0]]; o0.y = lut[v[1][s0]]; o0.z = lut[v[2][s0]]; o0.w = lut[v[3][s0]];
+            o1.x = lut[256 + v[0][1]]; o1.y = lut[256 + v[1][1]]; o1.z = lut[256 + v[2][1]]; o1.w = lut[256 + v[3][1]];
+            o2.x = lut[512 + v[0][s2]]; o2.y = lut[512 + v[1][s2]]; o2.z = lut[512 + v[2][s2]]; o2.w = lut[512 + v[3][s2]];
+            __builtin_nontemporal_store(o0, reinterpret_cast<vx_v4 *>(d));
+            __builtin_nontemporal_store(o1, reinterpret_cast<vx_v4 *>(d + HWd));
+            __builtin_nontemporal_store(o2, reinterpret_cast<vx_v4 *>(d + 2 * HWd));
+        } else {
+            unsigned *d = reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(dstv) + ((long long)b * HWd + (long long)y * r.Wd + x) * 3);
+            d[0] = (unsigned)v[0][0] | ((unsigned)v[0][1] << 8) | ((unsigned)v[0][2] << 16) | ((unsigned)v[1][0] << 24);
+            d[1] = (unsigned)v[1][1] | ((unsigned)v[1][2] << 8) | ((unsigned)v[2][0] << 16) | ((unsigned)v[2][1] << 24);
+            d[2] = (unsigned)v[2][2] | ((unsigned)v[3][0] << 8) | ((unsigned)v[3][1] << 16) | ((unsigned)v[3][2] << 24);
+        }
+    }
+}
+
+// shapes the streaming kernel takes (everything else keeps the one-pixel-per-thread kernels)
+static bool vx_resize_fast_ok(const vx_resize_params &r, const void *dst, bool norm) {
+    if ((r.Wd & 3) || r.Wd > VX_RS_MAXW || r.Ws < 3) return false;
+    if (norm) return (((uintptr_t)dst & 15) == 0) && (((long long)r.Hd * r.Wd) % 4 == 0);
+    return (((uintptr_t)dst & 3) == 0);              // 12-byte groups stay 4-byte aligned: (b*Hd*Wd + y*Wd + x) * 3, x % 4 == 0, Wd % 4 == 0
+}
+
 static inline int vx_grid_for(long long work_items, int block, int max_blocks) {
     long long g = (work_items + block - 1) / block;
     if (g > max_blocks) g = max_blocks;
@@ -255,6 +372,11 @@ extern "C" int vx_resize_u8hwc(const uint8_t *d_src, uint8_t *d_dst, int B, int 
     vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
     if ((long long)Hd * Wd >= (1LL << 30) || B > 65535) return VX_ERR_UNSUPPORTED;
     vx_prof_begin(VX_PROF_PREPROCESS, st);
+    if (vx_resize_fast_ok(r, d_dst, false)) {
+        vx_norm_params np = {};
+        hipLaunchKernelGGL(vx_k_resize_fast<false>, dim3((Hd + VX_RS_ROWS - 1) / VX_RS_ROWS, B), dim3(256), 0, st, d_src,
+                           (void *)d_dst, r, np);
+    } else
     hipLaunchKernelGGL(vx_k_resize_u8, dim3(vx_grid_for((long long)Hd * Wd, 1024, 4096), B), dim3(256), 0, st, d_src, d_dst, B, r);
     vx_prof_end(VX_PROF_PREPROCESS, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
@@ -299,6 +421,10 @@ extern "C" int vx_preprocess_u8hwc_f32nchw(const uint8_t *d_src, float *d_dst, i
     } else {
         vx_resize_params r = vx_make_resize(Hs, Ws, Hd, Wd, resize_mode, pad_value);
         if ((long long)Hd * Wd >= (1LL << 30) || B > 65535) { vx_prof_end(VX_PROF_PREPROCESS, st); return VX_ERR_UNSUPPORTED; }
+        if (vx_resize_fast_ok(r, d_dst, true))
+            hipLaunchKernelGGL(vx_k_resize_fast<true>, dim3((Hd + VX_RS_ROWS - 1) / VX_RS_ROWS, B), dim3(256), 0, st, d_src,
+                               (void *)d_dst, r, p);
+        else
         hipLaunchKernelGGL(vx_k_resize_normalize, dim3(vx_grid_for((long long)Hd * Wd, 1024, 4096), B), dim3(256), 0, st,
                            d_src, d_dst, B, r, p);
     }
