@@ -10,7 +10,14 @@ Workload: BASELINE.json configs[3] — YOLOv3 416x416, 80 classes, batch 256 per
 every rank processes its own 256-image shard; no data-path collective unless --allgather).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-For N>1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL)."""
+For N>1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL); started WITHOUT a launcher
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) it spawns the N ranks itself -- fresh child
+processes, before anything touches a GPU -- over RCCL when the node has N GPUs, else over gloo with ranks
+sharing the GPUs there are (rehearsal; the line says `"backend": "gloo"`).
+
+At N=1 the line also carries `configs`: the other BASELINE.json configurations (FPN-SSD b64, RetinaFace b128,
+NMS stress 100k, dense YOLO, 720p resize), each with images/s, roofline, NMS IoU-test throughput and a time-boxed
+CPU baseline (tools/bench_configs.py)."""
 import argparse
 import json
 import os
@@ -23,6 +30,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+CONFIG_NAMES = ("fpn_ssd_640_b64", "retinaface_640_b128", "nms_stress_100k_b32_top300", "yolo416_b256_dense",
+                "yolo416_b256_resize720p")
 S, C = 416, 80
 R = 10647
 ROW_BYTES = (5 + C) * 4
@@ -81,16 +90,42 @@ def cpu_baseline(sthr, ithr, budget_s=15.0, n_img=8):
                       "iterations on 1 thread, %.0f s)" % (n, n_img, sthr, ithr, dt, n1, dt1)}
 
 
+def spawn_ranks(n, argv):
+    """Self-contained multi-GPU launch: N fresh worker processes (this process never initialises a GPU), one rank
+    per GPU, rendezvous on 127.0.0.1.  Fewer GPUs than ranks -> gloo backend, ranks share GPUs (rehearsal only)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ndev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if ndev < n:
+            env.setdefault("VX_BENCH_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
 def load_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate runs,
-    profiles/traffic_*.json; corrected as MI355X_MICROARCH.md §HBM prescribes).  None if not measured."""
-    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    profiles/traffic_rNN.json, the newest round; corrected as MI355X_MICROARCH.md §HBM prescribes) and the file it
+    came from: (None, None) if not measured.  The number is NOT measured in this run; the line says so."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    if not files:
+        return None, None
     try:
-        with open(p) as f:
+        with open(files[-1]) as f:
             d = json.load(f)
-        return d.get(tag, {}).get("hbm_bytes_per_launch")
+        return d.get(tag, {}).get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -107,6 +142,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra pass that times the opt-in variants")
+    ap.add_argument("--configs", default="all",
+                    help="N=1 only: the other BASELINE configs measured as sub-records of the line: 'all', 'none' or a "
+                         "comma-separated list of " + ", ".join(CONFIG_NAMES))
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight: 1 = synchronous API call per step (forward()), 2 = forward_async(): "
                          "the launches of step i+1 are enqueued before the results of step i are collected")
@@ -120,10 +158,13 @@ def main():
     if args.dense:
         args.score_thr = 0.06
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves, as child processes, before any GPU call in this process
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus (or without a launcher)"
     dist = None
     # rehearsal knob (tests on a one-GPU box): VX_BENCH_BACKEND=gloo lets several ranks share a GPU
     backend = os.environ.get("VX_BENCH_BACKEND", "nccl")
@@ -271,10 +312,13 @@ def main():
         del graphed
         post = post_full
 
+    rank_dt = [dt]
     if dist is not None:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_dt = [float(v.item()) for v in allt]
+        dt = max(rank_dt)                                   # whole-job time = the slowest rank
 
     result = None
     if rank == 0:
@@ -287,10 +331,12 @@ def main():
             avg_ms = kern[dom]["avg_ms"]
             algo = B * ALGO_BYTES_DECODE + 32 * cand
             ach = algo / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_file = load_traffic("unfused" if args.unfused else ("dense" if args.dense else "default"))
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(avg_ms, 5),
-                    "algorithmic_bytes_per_launch": algo,
-                    "traffic": load_traffic("unfused" if args.unfused else ("dense" if args.dense else "default"))}
+                    "algorithmic_bytes_per_launch": algo, "traffic": traffic,
+                    "traffic_source": ("%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE doubled as the "
+                                       "guide prescribes); not measured in this run" % traffic_file) if traffic else None}
         pipe_bytes = B * ((ALGO_BYTES_PRE + ALGO_BYTES_DECODE) if not args.unfused
                           else (ALGO_BYTES_PRE + 3 * ALGO_BYTES_DECODE))
         result = {
@@ -309,6 +355,11 @@ def main():
                                       % (n_gpus, "; all-gather of results" if args.allgather else ""),
                        "batches_in_flight": 1 if args.allgather else args.depth,
                        "hip_streams": 2 if two_streams else 1},
+            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "single process",
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
+            "per_rank_images_per_s": [round(B * args.steps / t_, 1) for t_ in rank_dt],
+            "step_ms_min_max_over_ranks": [round(min(rank_dt) / args.steps * 1e3, 4), round(max(rank_dt) / args.steps * 1e3, 4)],
+            "timed_region_ms": round(dt * 1e3, 2),
             "pipeline_hbm": {"algorithmic_bytes_per_step": pipe_bytes,
                              "achieved_GBps_per_gpu": round(pipe_bytes * args.steps / dt / 1e9, 1),
                              "frac_of_8TBps": round(pipe_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
@@ -322,6 +373,13 @@ def main():
             cb = cpu_baseline(args.score_thr, args.iou_thr)
             result["cpu_baseline"] = cb
             result["speedup_vs_cpu_port"] = round(ips / cb["value"], 1)
+        if n_gpus == 1 and args.configs != "none" and not (args.unfused or args.allgather):
+            # the other BASELINE configurations, each measured here with its own roofline / NMS rate / CPU baseline
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            names = list(CONFIG_NAMES) if args.configs == "all" else [n for n in args.configs.split(",") if n]
+            result["configs"] = bench_configs.run_configs(names, cpu=not args.no_cpu_baseline)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

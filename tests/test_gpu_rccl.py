@@ -58,3 +58,26 @@ def test_allgather_detections_over_rccl_world1():
         p.join(30)
         if p.is_alive():
             p.kill()
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two fresh rank processes itself (before
+    any GPU call in the parent); on a one-GPU box they share the GPU over gloo and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "16", "--no-cpu-baseline", "--no-variants", "--configs", "none"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    import torch
+    assert rec["n_gpus"] == 2 and len(rec["per_rank_images_per_s"]) == 2
+    assert rec["backend"] == ("rccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert rec["config"]["global_batch"] == 32 and rec["value"] > 0
+    assert rec["step_ms_min_max_over_ranks"][0] <= rec["step_ms_min_max_over_ranks"][1]

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Throughput of the other BASELINE.json configurations (parity-test cases, not the bench line):
-FPN-SSD 640 b64, RetinaFace 640 b128, NMS stress 100k x 80 classes b32, YOLOv3-416 b1 (latency).
-Prints one JSON line per configuration with per-kernel times from the library's HIP-event hooks."""
+"""The other BASELINE.json configurations as measured sub-records of bench.py's line (and as a CLI):
+  fpn_ssd_640_b64             FPN-SSD 640x640, 20 classes, batch 64: normalize + prior-box decode + class-aware NMS
+  retinaface_640_b128         RetinaFace 640x640, 5 landmarks, batch 128: normalize + prior-box decode + NMS
+  nms_stress_100k_b32_top300  100 000 boxes/image, 80 classes, top-k 300, batch 32: NMS only
+  yolo416_b256_dense          the headline pipeline at score_thr 0.06 (2 800 candidates/image)
+  yolo416_b256_resize720p     the headline pipeline fed 720x1280 uint8 frames (resize fused into the normalize)
+Each record carries images/s, per-kernel times (the library's HIP-event hooks), the roofline of its dominant
+HBM-bound kernel, the NMS throughput in executed IoU tests/s against the VALU peak, and a time-boxed CPU baseline
+(the oracle, on a bounded sample).  Inputs are synthetic (SURVEY §8d distributions) and resident in HBM."""
 import json
 import os
 import sys
@@ -10,30 +16,83 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import bench  # noqa: E402
-import vortex_amd as V  # noqa: E402
-from vortex_amd import _lib as L, ops  # noqa: E402
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# VALU peak for the IoU test: 256 CUs x 128 fp32 lanes/clk (the guide's 157.3 TFLOP/s vector peak / 2) x 2.4 GHz,
+# divided by the 13 lane-operations of one test in the sweep's inner loop (4 min/max, 2 sub, 1 max, 2 mul, 2 add/sub,
+# 1 sub, 1 max-accumulate; vx_async_cand in vx_nms.hip)
+VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9
+IOU_LANE_OPS = 13
+IOU_PEAK_TESTS_PER_S = VALU_LANE_OPS_PER_S / IOU_LANE_OPS
 
-dev = torch.device("cuda:0")
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
 
 
-def run(name, fn, images, steps=20, warmup=3, extra=None):
+def _timed(fn, steps, warmup):
+    from vortex_amd import _lib as L
     for _ in range(warmup):
-        fn()
+        out = fn()
     torch.cuda.synchronize()
-    L.profile_enable(steps * 40)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    L.profile_enable(steps * 40)                      # separate pass: every kernel family bracketed by HIP events
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
     kern = L.profile_read()
     L.profile_disable()
-    d = {"config": name, "images_per_s": round(images / dt, 1), "ms_per_step": round(dt * 1e3, 4),
-         "kernels_ms_total_per_step": {k: round(v["total_ms"] / steps, 5) for k, v in kern.items()}}
-    if extra:
-        d.update(extra(out))
-    print(json.dumps(d), flush=True)
+    return out, dt, {k: round(v["avg_ms"] * v["launches"] / steps, 5) for k, v in kern.items()}
+
+
+def _iou_tests(fn):
+    """IoU tests the NMS sweeps execute on live lanes in ONE step (device counter, vx_profile_set_iou_counter)."""
+    from vortex_amd import _lib as L
+    cnt = torch.zeros(1, dtype=torch.int64, device=_dev())
+    L.check(L.lib().vx_profile_set_iou_counter(cnt.data_ptr()), "vx_profile_set_iou_counter")
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.lib().vx_profile_set_iou_counter(None), "vx_profile_set_iou_counter")
+    return int(cnt.item())
+
+
+def _nms_record(tests, nms_ms):
+    if not tests or not nms_ms:
+        return None
+    rate = tests / (nms_ms * 1e-3)
+    return {"iou_tests_per_step": tests, "nms_kernels_ms": round(nms_ms, 5), "iou_tests_per_s": round(rate, 1),
+            "valu_peak_tests_per_s": IOU_PEAK_TESTS_PER_S, "frac_of_valu_peak": round(rate / IOU_PEAK_TESTS_PER_S, 4),
+            "note": "live-lane IoU tests counted on the device / summed NMS kernel time; peak = 256 CU x 128 lanes/clk x "
+                    "2.4 GHz / 13 lane-ops per test"}
+
+
+def _roof(kernel, ms, algo_bytes):
+    ach = algo_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": int(algo_bytes),
+            "traffic": None, "traffic_source": "not collected in this run (PMC passes are separate rocprofv3 runs: profiles/)"}
+
+
+NMS_KERNELS = ("vx_k_nms_image", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather", "vx_k_nms_sweep", "vx_k_sort(keys2)+output")
+
+
+def _cpu(fn, images, budget_s, what):
+    """fn() processes `images` images on the host (the oracle); repeated while the budget lasts (at least once)."""
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * images / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s, %d run(s) x %d image(s), %.1f s" % (what, n, images, dt)}
 
 
 def make_priors(img_size=640):
@@ -52,11 +111,16 @@ def make_priors(img_size=640):
     return torch.cat(out, 0).float().contiguous()
 
 
-def prior_cfg(name, B, Lm, NL, sthr):
+def prior_cfg(B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
+    import vortex_amd as V
+    from vortex_amd import ops
+    dev = _dev()
     P = 50400
-    priors = make_priors(640).to(dev)
+    priors_h = make_priors(640)
+    priors = priors_h.to(dev)
     g = torch.Generator(device=dev).manual_seed(5)
-    x = torch.randn(B, P, 4 + 2 * Lm + NL, generator=g, device=dev)
+    NCOL = 4 + 2 * Lm + NL
+    x = torch.randn(B, P, NCOL, generator=g, device=dev)
     x[..., 4 + 2 * Lm + 1:] = x[..., 4 + 2 * Lm + 1:] * 2 - 3
     img = torch.randint(0, 256, (B, 640, 640, 3), generator=g, dtype=torch.uint8, device=dev)
     norm = V.Normalize([0.5] * 3, [0.5] * 3).to(dev)
@@ -66,12 +130,27 @@ def prior_cfg(name, B, Lm, NL, sthr):
     def fn():
         norm(img)
         return pp(x, st, it)
-    algo = B * (15 * 640 * 640 + P * (4 + 2 * Lm + NL) * 4) + P * 16
-    run(name, fn, B, extra=lambda out: {"detections_per_batch": sum(int(r.shape[0]) for r in out),
-                                        "algorithmic_bytes_per_step": algo})
+    out, dt, kern = _timed(fn, steps, warmup)
+    cand = int(ops.prior_decode(x, priors, Lm, sthr).counts.sum())
+    algo = B * P * NCOL * 4 + P * 16 + cand * (32 + 8 * Lm)         # rows + priors once + staged survivor records
+    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
+           "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
+           "thresholds": {"score": sthr, "iou": 0.4},
+           "roofline": _roof("vx_k_prior_decode", kern["vx_k_prior_decode"], algo)}
+    tests = _iou_tests(fn)
+    rec["nms"] = _nms_record(tests, sum(kern.get(k, 0.0) for k in NMS_KERNELS))
+    if cpu_budget:
+        from oracle import vortex_oracle as O
+        xh = x[:1].cpu()
+        imh = img[:1].cpu()
+        rec["cpu_baseline"] = _cpu(lambda: (O.normalize(imh, [0.5] * 3, [0.5] * 3), O.prior_postprocess(xh, priors_h, st, it, Lm)),
+                                   1, cpu_budget, "oracle normalize + prior-box decode + NMS on image 0 of the same batch")
+    return rec
 
 
-def stress_cfg():
+def stress_cfg(steps=10, warmup=3, cpu_budget=1.0):
+    from vortex_amd import ops
+    dev = _dev()
     B, K, C = 32, 100_000, 80
     g = torch.Generator(device=dev).manual_seed(9)
     c = torch.rand(B, K, 2, generator=g, device=dev)
@@ -83,37 +162,107 @@ def stress_cfg():
 
     def fn():
         return ops.batched_nms(boxes, scores, cls, det, None, 0.45, C, 300)
-    # NMS is not HBM-bound -> report pair evaluations.  Upper bound = sum over (image, class) of
-    # n_c (n_c - 1) / 2 (every pair of a class segment); the greedy sweep skips pairs whose first box is suppressed.
-    cnt = torch.zeros(B, C, device=dev).scatter_add_(1, cls, torch.ones_like(cls, dtype=torch.float32))
-    pairs = float((cnt * (cnt - 1) / 2).sum())
-    run("nms_stress_100k_c80_b32_top300", fn, B,
-        extra=lambda out: {"kept_per_image_after_topk": float(out[2].float().mean()),
-                           "class_pair_upper_bound_per_step": pairs})
+    out, dt, kern = _timed(fn, steps, warmup)
+    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
+           "boxes_per_image": K, "classes": C, "top_k": 300, "thresholds": {"score": 0.001, "iou": 0.45},
+           "kept_per_image": float(out[2].float().mean())}
+    rec["nms"] = _nms_record(_iou_tests(fn), sum(kern.get(k, 0.0) for k in NMS_KERNELS))
+    # NMS is VALU-bound, not HBM-bound: its roofline is the IoU-test rate above; the bytes it must move
+    # (keys, boxes, output rows) are reported for completeness
+    rec["roofline"] = {"bound": "valu", "kernel": "vx_k_part_sweep (reported as vx_k_nms_sweep)", "achieved": rec["nms"]["iou_tests_per_s"],
+                       "peak": IOU_PEAK_TESTS_PER_S, "unit": "IoU tests/s", "frac": rec["nms"]["frac_of_valu_peak"]}
+    if cpu_budget:
+        from oracle import vortex_oracle as O
+        bh, sh, ch = boxes[0].cpu(), scores[0].cpu(), cls[0].cpu()
+        rec["cpu_baseline"] = _cpu(lambda: O.batched_nms(bh, sh, ch, torch.tensor([0.45]))[:300], 1, cpu_budget,
+                                   "oracle batched_nms (single-thread C greedy NMS) on image 0 of the same batch, all "
+                                   "100 000 boxes, then the first 300")
+    return rec
 
 
-def yolo_b1():
-    img, heads = bench.synth_on_device(1, dev, 1)
-    norm = V.Normalize().to(dev)
-    post = V.YoloV3FusedPostProcess(img_size=416)
-    st, it = torch.tensor([0.9]), torch.tensor([0.2])
+def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
+    """kind = 'dense' (score_thr 0.06) or 'resize720p' (720x1280 frames resized inside the pre-process)."""
+    import bench
+    import vortex_amd as V
+    from vortex_amd import ops
+    dev = _dev()
+    B, S, C = 256, 416, 80
+    img, heads = bench.synth_on_device(B, dev, seed=4321)
+    sthr = 0.06 if kind == "dense" else 0.9
+    st, it = torch.tensor([sthr]), torch.tensor([0.2])
+    post = V.YoloV3FusedPostProcess(img_size=S)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    if kind == "resize720p":
+        g = torch.Generator(device=dev).manual_seed(11)
+        frames = torch.randint(0, 256, (B, 720, 1280, 3), generator=g, dtype=torch.uint8, device=dev)
+
+        def pre():
+            return ops.preprocess(frames, mean, std, 255, out_size=(S, S))
+    else:
+        norm = V.Normalize(mean, std).to(dev)
+
+        def pre():
+            return norm(img)
 
     def fn():
-        norm(img)
+        pre()
         return post(heads, st, it)
-    run("yolov3_416_b1_latency", fn, 1, steps=200, warmup=20)
-    from vortex_amd.graphs import GraphedPostProcess
-    g = GraphedPostProcess(post, heads, st, it, preprocess=norm, images=img)
-    run("yolov3_416_b1_latency_hipgraph", lambda: g(), 1, steps=200, warmup=20)
+    out, dt, kern = _timed(fn, steps, warmup)
+    cand = int(ops.yolo_fused_decode(heads, S, sthr).counts.sum())
+    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
+           "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
+           "thresholds": {"score": sthr, "iou": 0.2}}
+    if kind == "resize720p":
+        rec["roofline"] = _roof("vx_k_resize_fast (reported as vx_k_normalize/resize)", kern["vx_k_normalize/resize"],
+                                B * (3 * 720 * 1280 + 12 * S * S))
+    else:
+        rec["roofline"] = _roof("vx_k_yolo_fused", kern["vx_k_yolo_fused"], B * bench.ALGO_BYTES_DECODE + 32 * cand)
+    rec["nms"] = _nms_record(_iou_tests(fn), sum(kern.get(k, 0.0) for k in NMS_KERNELS))
+    if cpu_budget:
+        from oracle import vortex_oracle as O
+        n = 2
+        hh = [h[:n].cpu() for h in heads]
+        if kind == "resize720p":
+            fr = frames[:n].cpu().numpy()
+
+            def cpu():
+                import numpy as np
+                x = torch.from_numpy(np.stack([O.resize_bilinear_u8(f, S, S) for f in fr]))
+                return O.normalize(x, mean, std), O.yolo_postprocess(O.yolo_head_eval(hh, S), st, it, S)
+        else:
+            ih = img[:n].cpu()
+
+            def cpu():
+                return O.normalize(ih, mean, std), O.yolo_postprocess(O.yolo_head_eval(hh, S), st, it, S)
+        rec["cpu_baseline"] = _cpu(cpu, n, cpu_budget, "oracle pre-process + head decode + decoder + NMS on images 0-1 of the same batch")
+    return rec
+
+
+CONFIGS = {
+    "fpn_ssd_640_b64": lambda **kw: prior_cfg(64, 0, 21, 0.3, **kw),
+    "retinaface_640_b128": lambda **kw: prior_cfg(128, 5, 2, 0.5, **kw),
+    "nms_stress_100k_b32_top300": lambda **kw: stress_cfg(**kw),
+    "yolo416_b256_dense": lambda **kw: yolo_cfg("dense", **kw),
+    "yolo416_b256_resize720p": lambda **kw: yolo_cfg("resize720p", **kw),
+}
+
+
+def run_configs(names=None, cpu=True):
+    out = {}
+    for name in (names or CONFIGS):
+        kw = {} if cpu else {"cpu_budget": 0}
+        try:
+            out[name] = CONFIGS[name](**kw)
+        except Exception as e:                                  # a failed sub-record must not take the headline line down
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ssd", "retinaface", "stress", "b1"]
-    if "ssd" in which:
-        prior_cfg("fpn_ssd_640_b64_c20", 64, 0, 21, 0.3)
-    if "retinaface" in which:
-        prior_cfg("retinaface_640_b128_l5", 128, 5, 2, 0.5)
-    if "stress" in which:
-        stress_cfg()
-    if "b1" in which:
-        yolo_b1()
+    alias = {"ssd": "fpn_ssd_640_b64", "retinaface": "retinaface_640_b128", "stress": "nms_stress_100k_b32_top300",
+             "dense": "yolo416_b256_dense", "resize": "yolo416_b256_resize720p"}
+    args = [a for a in sys.argv[1:] if a != "--no-cpu"]
+    which = [alias.get(a, a) for a in args] or list(CONFIGS)
+    for k, v in run_configs(which, cpu="--no-cpu" not in sys.argv).items():
+        print(json.dumps({"config": k, **v}), flush=True)

@@ -463,13 +463,14 @@ __device__ __forceinline__ void vx_build_pair_lut(unsigned short *lut) {
 __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
                                                const u64 *keys1, int lo, int n, const vx_thr &thr, u64 *wmask,
                                                const unsigned short *pair_lut, u64 *__restrict__ keys2,
-                                               int *count2) {
+                                               int *count2, unsigned long long *iou_count = nullptr) {
     const int lane = vx_lane();
     vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
     float ar = 0.f;
     if (lane < n) { bx = sbox[lo + lane]; ar = sarea[lo + lane]; }
     u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     const int npairs = n * (n - 1) / 2;
+    if (iou_count && npairs > 0 && lane == 0) atomicAdd(iou_count, (unsigned long long)npairs);
     if (npairs > 0) {
         wmask[lane] = 0ull;
         __builtin_amdgcn_wave_barrier();
@@ -506,8 +507,10 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
 // Wave routine: a segment of n <= 64*WT boxes, everything in registers.
 __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
                                               const u64 *__restrict__ keys1, int lo, int n, const vx_thr &thr,
-                                              u64 *__restrict__ keys2, int *__restrict__ count2) {
+                                              u64 *__restrict__ keys2, int *__restrict__ count2,
+                                              unsigned long long *iou_count = nullptr) {
     const int lane = vx_lane();
+    unsigned long long tests = 0ull;
     float x1[VX_SWEEP_WT], y1[VX_SWEEP_WT], x2[VX_SWEEP_WT], y2[VX_SWEEP_WT], ar[VX_SWEEP_WT];
     bool alive[VX_SWEEP_WT];
 #pragma unroll
@@ -527,6 +530,12 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
                 int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
                 float bx1 = vx_bcast(x1[t], i), by1 = vx_bcast(y1[t], i);
                 float bx2 = vx_bcast(x2[t], i), by2 = vx_bcast(y2[t], i), ba = vx_bcast(ar[t], i);
+                if (iou_count) {                       // live lanes behind box i (measurement only)
+                    tests += __popcll(todo & ~((2ull << i) - 1ull));
+#pragma unroll
+                    for (int u = 1; u < VX_SWEEP_WT; ++u)
+                        if (u > t && u * 64 < n) tests += __popcll(__ballot(alive[u]));
+                }
 #pragma unroll
                 for (int u = t; u < VX_SWEEP_WT; ++u) {
                     if (u * 64 < n) {
@@ -548,6 +557,7 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
             vx_emit_kept(m, alive[u], key, keys2, count2);
         }
     }
+    if (iou_count && tests && lane == 0) atomicAdd(iou_count, tests);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,7 +890,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
         int hi = c + 1 < VX_MAX_CLASSES ? vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52) : n;
         int len = hi - lo;
         if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, k1, lo, len, T, k2, c2);
+            vx_sweep_wave(sb, sa, k1, lo, len, T, k2, c2, iou_count);
         } else if (vx_lane() == 0) {
             int q = atomicAdd(&s_nbig, 1);
             s_big[q][0] = lo; s_big[q][1] = len;
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     u64 *k2 = a.keys2 + ob;
     int *c2 = a.count2 + b;
     if (!big) {
-        if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2);
+        if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count);
     } else {
         vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
         vx_async_emit(A, kseg, k2, c2);
@@ -1224,8 +1234,10 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
     const vx_thr T = vx_make_thr(p.thr);
     u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     u64 todo = alive;
+    unsigned long long tests = 0ull;
     while (todo) {                                   // wave-uniform: next still-alive box in sorted order
         const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+        if (a.iou_count) tests += __popcll(__ballot(valid && lane > i && cl == __builtin_amdgcn_readlane(cl, i)) & alive);
         const float ix1 = vx_bcast(bx.x, i), iy1 = vx_bcast(bx.y, i), ix2 = vx_bcast(bx.z, i), iy2 = vx_bcast(bx.w, i);
         const float ia = vx_bcast(ar, i);
         const int ci = __builtin_amdgcn_readlane(cl, i);
@@ -1233,6 +1245,7 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
         alive &= ~__ballot(sup);
         todo = alive & ~((2ull << i) - 1ull);
     }
+    if (a.iou_count && tests && lane == 0) atomicAdd(a.iou_count, tests);
     const bool kept = (alive >> lane) & 1ull;
     u64 k2 = kept ? vx_key2_from_key1(key) : VX_KEY_SENTINEL;
     k2 = vx_wave_sort64(k2);                         // kept boxes of all classes back into score order
@@ -1354,9 +1367,9 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         int hi = s + 1 < nseg ? seg[s + 1] : n;
         int len = hi - lo;
         if (len <= 64) {
-            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, k2, &s_count2);
+            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, k2, &s_count2, a.iou_count);
         } else if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, sk, lo, len, T, k2, &s_count2);
+            vx_sweep_wave(sb, sa, sk, lo, len, T, k2, &s_count2, a.iou_count);
         } else if (lane == 0) {
             int q = atomicAdd(&s_nbig, 1);
             if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; }
