@@ -161,3 +161,24 @@ def test_graphed_postprocess_matches_eager_and_follows_its_inputs():
     pp = V.YoloV3PostProcess(64)
     g2 = GraphedPostProcess(pp, pred, 0.06, 0.2)
     assert all(torch.equal(a, b) for a, b in zip(g2(), pp(pred, torch.tensor([0.06]), torch.tensor([0.2]))))
+
+
+def test_graphed_postprocess_two_launches_in_flight_keep_their_own_results():
+    """launch(); new inputs; launch(); launch() -- and only then the results: every PendingDetections returns the
+    detections of the inputs ITS launch saw, although the third launch replays into the first one's buffers."""
+    from vortex_amd.graphs import GraphedPostProcess
+    S, C, B = 416, 80, 3
+    st, it = torch.tensor([0.5]), torch.tensor([0.3])
+    hs = [[h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=70 + k)] for k in range(3)]
+    post = V.YoloV3FusedPostProcess(S)
+    static = [h.clone() for h in hs[0]]
+    g = GraphedPostProcess(post, static, st, it, depth=2)
+    pend = []
+    for k in range(3):
+        for s_, h in zip(static, hs[k]):
+            s_.copy_(h)
+        pend.append(g.launch())
+    for k in (0, 1, 2):
+        exp = post(hs[k], st, it)
+        got = pend[k].result()
+        assert len(got) == B and all(torch.equal(a, b) for a, b in zip(got, exp)), "launch %d returned another batch" % k

@@ -16,14 +16,24 @@ from . import ops
 from .postprocess import PendingDetections, _f
 
 
+class _Captured:
+    """One captured chain with its static buffers (packed rows, meta words, pinned mirror, pre-process output)."""
+    __slots__ = ("graph", "preprocessed", "packed", "meta", "host", "pending")
+
+
 class GraphedPostProcess:
     """graph = GraphedPostProcess(post, inputs, score_threshold, iou_threshold[, preprocess, images]);
     fill `inputs` (and `images`) in place, then `graph()` -> tuple of per-image detections (fresh tensors),
     or `graph.launch()` -> PendingDetections to overlap the wait with other work.  `graph.preprocessed` is the
-    static output of the captured pre-process (input of the backbone)."""
+    static output of the last launched pre-process (input of the backbone).
+
+    `depth` launches may be in flight: the chain is captured `depth` times, each capture with its own static output
+    buffers and pinned mirror, used round-robin.  A launch that comes back to a buffer set whose previous result has
+    not been collected yet first waits for that launch and copies its rows out, so an uncollected PendingDetections
+    never changes under its owner."""
 
     def __init__(self, post, inputs: Union[torch.Tensor, Sequence[torch.Tensor]], score_threshold, iou_threshold,
-                 preprocess=None, images: Optional[torch.Tensor] = None, warmup: int = 3):
+                 preprocess=None, images: Optional[torch.Tensor] = None, warmup: int = 3, depth: int = 2):
         if not hasattr(post, "forward_unpacked"):
             raise RuntimeError("GraphedPostProcess needs a post-process with forward_unpacked (BatchedNMSPostProcess family)")
         self.post, self.inputs, self.images, self.preprocess = post, inputs, images, preprocess
@@ -31,41 +41,64 @@ class GraphedPostProcess:
         first = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
         self.device = first.device
         self.preprocessed = None
-        # pinned mirror of the counts/status words: allocated before the capture (no host allocation inside it)
-        self._host = torch.empty((2 * first.size(0) + 1,), dtype=torch.int32, pin_memory=True)
+        self._n = 0
+        self._sets = []
         side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):                       # warm-up off the capture (allocator pools, lazy init)
-            for _ in range(max(warmup, 1)):
-                self._chain()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.preprocessed, self._packed, self._meta = self._chain()
+        for i in range(max(int(depth), 1)):
+            c = _Captured()
+            # pinned mirror of the counts/status words: allocated before the capture (no host allocation inside it)
+            c.host = torch.empty((2 * first.size(0) + 1,), dtype=torch.int32, pin_memory=True)
+            c.pending = None
+            if i == 0:
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):               # warm-up off the capture (allocator pools, lazy init)
+                    for _ in range(max(warmup, 1)):
+                        self._chain(c.host)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+            c.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(c.graph):
+                c.preprocessed, c.packed, c.meta = self._chain(c.host)
+            self._sets.append(c)
+        self.preprocessed = self._sets[0].preprocessed
 
-    def _chain(self):
+    def _chain(self, host):
         x = self.preprocess(self.images) if (self.preprocess is not None and self.images is not None) else None
         out_det, keep_counts, meta = self.post.forward_unpacked(self.inputs, self._sthr, self._ithr)
-        packed = ops.pack_rows(out_det, keep_counts, meta, self._host)
+        packed = ops.pack_rows(out_det, keep_counts, meta, host)
         return x, packed, meta
 
     def launch(self) -> PendingDetections:
-        self.graph.replay()
-        return _GraphPending(self._packed, self._meta, self._host)
+        c = self._sets[self._n % len(self._sets)]
+        self._n += 1
+        if c.pending is not None:
+            c.pending.detach()                              # its rows leave the static buffer before the replay rewrites it
+        c.graph.replay()
+        self.preprocessed = c.preprocessed
+        c.pending = _GraphPending(c.packed, c.meta, c.host)
+        return c.pending
 
     def __call__(self) -> Tuple[torch.Tensor, ...]:
         return self.launch().result()
 
 
 class _GraphPending(PendingDetections):
-    """The packed rows live in the graph's static buffer: result() hands out copies, so the next replay cannot
-    change detections the caller still holds."""
+    """The packed rows live in a static buffer of the graph: result() hands out copies, and detach() -- called by
+    the owner graph before it replays into the same buffers -- takes them early, so a later replay cannot change
+    detections somebody still holds or has yet to collect."""
+    _rows = None
+    _counts = None
+
+    def detach(self):
+        if self._counts is None:
+            self._event.synchronize()
+            m = self._host.tolist()
+            B = (len(m) - 1) // 2
+            self._status, self._counts = int(m[-1]), m[B:2 * B]
+            self._rows = self.packed[:sum(self._counts)].clone()
+            torch.cuda.current_stream(self._rows.device).synchronize()      # the copy is done before anything replays
 
     def result(self):
-        self._event.synchronize()
-        m = self._host.tolist()
-        B = (len(m) - 1) // 2
-        ops.raise_on_status(int(m[-1]))
-        kc = m[B:2 * B]
-        return tuple(self.packed[:sum(kc)].clone().unsafe_split_with_sizes(kc))
+        self.detach()
+        ops.raise_on_status(self._status)
+        return tuple(self._rows.unsafe_split_with_sizes(self._counts))

@@ -1,85 +1,77 @@
-"""Callers of the hot path, kept API-compatible with the reference:
-  predictor/base_module.py:9-113   BasePredictor (preprocess -> model -> postprocess), create_predictor
-  predictor/utils.py:11-33         get_prediction_results (np.take per output_format key)
-The model (backbone + head convs) is any torch nn.Module running on PyTorch-ROCm."""
+"""The build's own minimal caller of the hot path (tests, bench, examples).
+
+Vortex's `BasePredictor` (reference predictor/base_module.py:9-113) is NOT re-implemented here: it is plain Python
+that composes whatever pre-process / network / post-process modules it is given, so it runs unchanged on top of
+`vortex_amd.Normalize`, `vortex_amd.YoloV3PostProcess`, ....  What this file offers instead:
+
+  Pipeline              pre-process -> network -> post-process as one nn.Module, nothing else; `detect()` adds the
+                        on-device result formatting of vortex_amd.runtime (output_format columns, pixel scaling)
+  create_predictor      builds a Pipeline from a dict / namespace of components (the shape of the reference's
+                        `create_model_components` result, models/detection/yolov3.py:94-112)
+  get_prediction_results  host-side column slicing with the contract of reference predictor/utils.py:11-33
+                        (np.take per output_format key, None for an empty result)
+
+`BasePredictor` is kept as an alias of Pipeline so existing imports keep working."""
 from collections import OrderedDict
-from typing import Dict, List, Type, Union
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from .postprocess import NoOpPostProcess
 
-
-class BasePredictor(nn.Module):
-    postprocess_signature = {'input': torch.Tensor, 'return': Union[torch.Tensor, List[torch.Tensor]]}
-    preprocess_signature = {'input': torch.Tensor, 'return': torch.Tensor}
-
-    def __init__(self, model: Type[nn.Module], preprocess: Union[Type[nn.Module]] = None,
-                 postprocess: Union[Type[nn.Module]] = None):
-        super(BasePredictor, self).__init__()
+class Pipeline(nn.Module):
+    def __init__(self, model: nn.Module, preprocess: Optional[nn.Module] = None, postprocess: Optional[nn.Module] = None):
+        super().__init__()
+        self.preprocess = preprocess if preprocess is not None else nn.Identity()
         self.model = model
-        if preprocess is None:
-            preprocess = nn.Identity()
-        if postprocess is None:
-            postprocess = NoOpPostProcess()
-        self.preprocess = preprocess
         self.postprocess = postprocess
-        self.task = model.task
-        if type(self.postprocess) != NoOpPostProcess:
-            if not len(self.postprocess.forward.__annotations__):
-                raise RuntimeError("please annotate postprocess with %s" % BasePredictor.postprocess_signature.keys())
-        if type(self.preprocess) != nn.modules.linear.Identity:
-            if not len(self.preprocess.forward.__annotations__):
-                raise RuntimeError("please annotate postprocess with %s" % BasePredictor.preprocess_signature.keys())
-            annotations = self.preprocess.forward.__annotations__
-            for key, value in BasePredictor.preprocess_signature.items():
-                if key not in annotations.keys():
-                    raise TypeError("missing preprocess annotation(s) : %s" % key)
-                if value != annotations[key]:
-                    raise TypeError("type mismatch for `%s`, expects %s got %s" % (key, value, annotations[key]))
-        assert hasattr(self.model, 'output_format'), f"model definition '{type(model)}' doesn't have 'output_format' attribute"
-        self.output_format = dict(self.model.output_format)
-        if self.task == "detection":
-            required = ["bounding_box", "class_confidence"]
-        elif self.task == "classification":
-            required = ["class_label", "class_confidence"]
-        else:
-            raise RuntimeError("unknown task of '%s'" % self.task)
-        for elem in required:
-            if elem not in self.output_format:
-                raise RuntimeError("expects output_format for task %s to have `%s` key, got output_format: %s" % (
-                    self.task, elem, self.output_format))
+        # the column map of the result rows travels with the network (reference models/detection/yolov3.py:56-60)
+        self.output_format = dict(getattr(model, "output_format", {}))
+        self.task = getattr(model, "task", "detection")
         self.eval()
 
-    def forward(self, input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
-        x = self.preprocess(input)
-        x = self.model(x)
-        x = self.postprocess(x, *args, **kwargs)
-        return x
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor, *args, **kwargs):
+        x = self.model(self.preprocess(input))
+        return x if self.postprocess is None else self.postprocess(x, *args, **kwargs)
+
+    def detect(self, input: torch.Tensor, *args, image_sizes: Optional[Sequence] = None, **kwargs) -> List[Dict[str, np.ndarray]]:
+        """forward() + the reference's result dictionaries; with `image_sizes` (images or (h, w) sizes) the coordinates come back in
+        pixels (InferenceHelper.adjust_coordinates).  Formatting runs on the device when the post-process offers the
+        unpacked path (vortex_amd.runtime.format_detections), else on the host."""
+        from . import runtime
+        x = self.model(self.preprocess(input))
+        if hasattr(self.postprocess, "forward_unpacked") and image_sizes is not None:
+            out_det, keep_counts, meta = self.postprocess.forward_unpacked(x, *args, **kwargs)
+            return runtime.format_detections(out_det, keep_counts, self.output_format, batch_vis=image_sizes,
+                                             coordinate_fmt="relative", status=meta[-1:])
+        return get_prediction_results(self.postprocess(x, *args, **kwargs), self.output_format)
 
 
-def create_predictor(model_components, **kwargs):
-    get = (lambda k: model_components[k] if k in model_components else None) if isinstance(model_components, dict) \
-        else (lambda k: getattr(model_components, k, None))
-    return BasePredictor(get("network"), preprocess=get("preprocess"), postprocess=get("postprocess"))
+BasePredictor = Pipeline
 
 
-def get_prediction_results(results, output_format: Dict[str, dict]) -> List[Dict[str, np.ndarray]]:
-    fmt = {}
-    for k, v in output_format.items():
-        ind = v["indices"]
-        if isinstance(ind, dict):
-            ind = [x for x in range(ind['start'], ind['end'])]
-        fmt[k] = (ind, v["axis"])
-    output_fields = sorted(fmt.keys())
-    final_results = []
-    for result in results:
-        if isinstance(result, torch.Tensor):
-            result = result.detach().cpu().numpy()
-        temp = OrderedDict()
-        for key in output_fields:
-            temp[key] = np.take(result, indices=fmt[key][0], axis=fmt[key][1]) if all(result.shape) else None
-        final_results.append(temp)
-    return final_results
+def create_predictor(model_components, **kwargs) -> Pipeline:
+    def pick(name):
+        if isinstance(model_components, dict):
+            return model_components.get(name)
+        return getattr(model_components, name, None)
+    return Pipeline(pick("network"), preprocess=pick("preprocess"), postprocess=pick("postprocess"))
+
+
+def _columns(spec) -> List[int]:
+    ind = spec["indices"]
+    return list(range(ind["start"], ind["end"])) if isinstance(ind, dict) else list(ind)
+
+
+def get_prediction_results(results, output_format: Dict[str, dict]) -> List[Dict[str, Optional[np.ndarray]]]:
+    plan = [(name, _columns(spec), spec["axis"]) for name, spec in sorted(output_format.items())]
+    out = []
+    for res in results:
+        arr = res.detach().cpu().numpy() if torch.is_tensor(res) else np.asarray(res)
+        row = OrderedDict()
+        for name, cols, axis in plan:
+            row[name] = None if arr.size == 0 else np.take(arr, cols, axis=axis)
+        out.append(row)
+    return out
