@@ -4,9 +4,14 @@
  * The drop-in boundary for Vortex's detection pre/post-process path.  Plain
  * pointers and sizes only; every pointer named `d_*` is DEVICE memory, every
  * other pointer is HOST memory read before the call returns.  `stream` is a
- * hipStream_t passed as void*.  No entry point allocates, frees or synchronises:
- * the caller owns outputs and workspace (sizes from the *_workspace_bytes
- * queries) and reads counts / status words back itself.
+ * hipStream_t passed as void*; kernels are launched on it with the CURRENT HIP
+ * device, which must be the device the pointers live on.  No entry point
+ * allocates, frees or synchronises: the caller owns outputs and workspace (sizes
+ * from the *_workspace_bytes queries) and reads counts / status words back itself.
+ * Process-global state the library keeps (all per device, set up on first use,
+ * thread-safe): the "large dynamic LDS" attribute of four kernels, one hipEvent
+ * for vx_yolo_fused_postprocess_overlapped, the address of the static scratch of
+ * vx_batched_nms_noalloc, and the opt-in profiling hooks.
  *
  * All reference citations are relative to
  *   /root/reference/src/development/vortex/development/   (unless they start with src/runtime)
@@ -37,8 +42,12 @@ extern "C" {
 /* bits of the device status word (int32, caller zeroes it, kernels OR into it) */
 #define VX_STATUS_NAN         1     /* predictions contain NaN: postprocess/yolov3.py:35-36 -> ValueError */
 #define VX_STATUS_BAD_CLASS   2     /* class index outside [0, n_classes) (n_classes <= 0: [0, VX_MAX_CLASSES)) */
-#define VX_STATUS_RANGE       4     /* NMS: |box coordinate| >= 1024 with more than one class: the per-class
-                                       sweep would differ from the reference's shifted single pass -> refused */
+#define VX_STATUS_RANGE       4     /* NMS, more than one class: some box coordinate lies outside (-1024, 1024) */
+#define VX_STATUS_RANGE2      16    /* NMS, more than one class: some box coordinate lies outside [0, 2048]
+                                       (VX_MAX_COORDINATE).  The per-class sweep equals the reference's single pass over
+                                       2049*class-shifted boxes while EVERY coordinate of an image batch stays in ONE of
+                                       the two ranges (normalised boxes / pixel boxes up to max_coordinate): a caller
+                                       refuses the result only when BOTH bits are set */
 #define VX_STATUS_DEFERRED    8     /* vx_batched_nms_small: some image had more candidates than the single-launch
                                        kernel sorts (16384); repeat the call with vx_batched_nms */
 
@@ -157,8 +166,10 @@ int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
  * top_k > 0 truncates each keep list to its first top_k entries (build-side extension);
  * out_capacity >= min(capacity, top_k>0 ? top_k : capacity).
  * Limits: capacity <= VX_MAX_CANDIDATES, 0 <= cls < n_classes <= VX_MAX_CLASSES (else VX_STATUS_BAD_CLASS),
- * |coordinate| < 1024 so that classes cannot overlap after the offset (always true for
- * normalised boxes; checked on the device -> VX_STATUS_RANGE), iou_threshold >= 0.
+ * every coordinate in (-1024, 1024) or every coordinate in [0, 2048] so that classes cannot overlap after the
+ * offset (checked on the device -> VX_STATUS_RANGE / VX_STATUS_RANGE2, see there), iou_threshold >= 0 (taken as
+ * fp32: the reference hands torchvision a Python float, i.e. the fp32 IoU is compared with a double there; the two
+ * agree for thresholds that are fp32 values, e.g. fp32 tensors).
  * n_classes == 1 declares class-agnostic NMS (every cls must be 0): no shift, any coordinate range.
  * n_classes is the caller's bound on the class indices (<= 0: VX_MAX_CLASSES); with 4..256 declared classes
  * images beyond the single-launch kernel are partitioned by class before sorting (see vx_nms.hip). */

@@ -130,7 +130,7 @@ def ragged_case(seed):
         cls[0, : cap * 3 // 4] = C - 1                    # one long segment (beyond the LDS sort when cap > 21845)
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(torch.int32).to(DEV), thr, C, top_k)
-    ok = int(status.item()) == 0
+    ok = ops.status_ok(int(status.item()))
     kc = keep_counts.cpu().tolist()
     for b in range(B):
         n = int(counts[b])

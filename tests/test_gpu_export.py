@@ -41,3 +41,28 @@ def test_trace_records_the_op_and_hook_matches_module_path():
     got = post.nms(detections=det.to(DEV), class_indexes=cls.to(DEV), bboxes=boxes.to(DEV), scores=scores.to(DEV),
                    iou_threshold=torch.tensor([0.4]))
     assert torch.equal(got, ref)
+
+
+def test_tracing_the_postprocess_after_use_custom_ops_records_the_op():
+    """The reference's TorchScript exporter traces the whole predictor after swapping nms_fn
+    (exporter/torchscript.py:35-45): with the hook set, forward() runs the per-image composition through the
+    registered op, so the traced graph holds vortex_amd::batched_nms -- and the results equal the batched path's."""
+    S, C = 64, 3
+    pred = O.yolo_head_eval(O.synth_yolo_heads(1, S, C, seed=31), S).to(DEV)
+    st, it = torch.tensor([0.06]), torch.tensor([0.3])
+    post = V.YoloV3PostProcess(img_size=S)
+    ref = post(pred, st, it)
+    export.use_custom_ops(post)
+    got = post(pred, st, it)
+    assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.post = post
+
+        def forward(self, x):
+            return self.post(x, st, it)[0]
+
+    traced = torch.jit.trace(M(), (pred,), check_trace=False)
+    assert "vortex_amd::batched_nms" in str(traced.inlined_graph)

@@ -112,7 +112,7 @@ def test_nms_stress_100k_boxes_80_classes_topk300():
     keep_idx, out_det, keep_counts, status = ops.batched_nms(*args, ithr, C, topk)
     keep_all, _, keep_counts_all, _ = ops.batched_nms(*args, ithr, C, None)
     kc, kca = keep_counts.cpu().tolist(), keep_counts_all.cpu().tolist()
-    assert int(status.item()) == 0
+    assert ops.status_ok(int(status.item()))
     for b in range(B):
         assert kc[b] == min(topk, kca[b])
         assert torch.equal(keep_idx[b, :kc[b]], keep_all[b, :kc[b]]), "top-k is not a prefix of the full keep list"

@@ -80,7 +80,7 @@ def test_counts_outside_the_capacity_are_clamped(cap):
     counts = torch.tensor([-3, cap + 100, min(5, cap)], dtype=torch.int32)
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(DEV), 0.5, C, None)
-    assert int(status.item()) == 0
+    assert ops.status_ok(int(status.item()))
     kc = keep_counts.cpu().tolist()
     for b, n in enumerate([0, cap, min(5, cap)]):
         ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([0.5]))
@@ -107,7 +107,7 @@ def test_fuzz_ragged_batch_with_top_k(seed):
     thr = [0.3, 0.5, 0.0][seed % 3]
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(torch.int32).to(DEV), thr, C, top_k)
-    assert int(status.item()) == 0
+    assert ops.status_ok(int(status.item()))
     kc = keep_counts.cpu().tolist()
     for b in range(B):
         n = int(counts[b])
@@ -226,7 +226,7 @@ def test_class_partitioned_path_and_its_fallback(C, K, skew):
     counts = torch.tensor([K, K - 123], dtype=torch.int32)
     keep_idx, out_det, keep_counts, status = ops.batched_nms(
         boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), counts.to(DEV), 0.5, C, None)
-    assert int(status.item()) == 0
+    assert ops.status_ok(int(status.item()))
     kc = keep_counts.cpu().tolist()
     for b in range(B):
         n = int(counts[b])
@@ -266,6 +266,6 @@ def test_top_k_select_with_tied_scores(levels, top_k):
     ref = O.batched_nms(boxes[0], scores[0], cls[0], torch.tensor([0.5]))
     assert ref.numel() == K                                # nothing overlaps
     ref = ref[:top_k]
-    assert int(status.item()) == 0 and int(keep_counts[0]) == ref.numel()
+    assert ops.status_ok(int(status.item())) and int(keep_counts[0]) == ref.numel()
     assert torch.equal(keep_idx[0, :ref.numel()].cpu(), ref)
     assert torch.equal(out_det[0, :ref.numel()].cpu(), det[0][ref])

@@ -243,6 +243,11 @@ def test_nms_coordinate_range_guard():
     inside = (boxes * 800.0).contiguous()                                                    # |x| <= 920: accepted
     same(V.batched_nms(inside.to(DEV), scores.to(DEV), cls.to(DEV), torch.tensor([0.5])),
          O.batched_nms(inside, scores, cls, torch.tensor([0.5])))
+    # pixel boxes inside [0, 2048] (the reference's max_coordinate): classes stay apart after the 2049*class shift too
+    for bb, ss, cc in ((boxes, scores, cls), (big, bs, bc)):
+        pix = (bb.clamp(0.0, 1.0) * 2048.0).contiguous()
+        same(V.batched_nms(pix.to(DEV), ss.to(DEV), cc.to(DEV), torch.tensor([0.5])),
+             O.batched_nms(pix, ss, cc, torch.tensor([0.5])))
 
 
 def test_nms_class_agnostic_module():

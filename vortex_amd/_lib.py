@@ -16,6 +16,7 @@ VX_STATUS_NAN = 1
 VX_STATUS_BAD_CLASS = 2
 VX_STATUS_RANGE = 4
 VX_STATUS_DEFERRED = 8
+VX_STATUS_RANGE2 = 16
 VX_MAX_CLASSES = 4096
 VX_MAX_CANDIDATES = 1048575
 VX_RESIZE_STRETCH = 0

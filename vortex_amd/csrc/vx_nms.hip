@@ -40,6 +40,21 @@ struct vx_nms_params {
 __device__ __forceinline__ bool vx_box_in_range(const vx_f4 &b) {
     return !(fabsf(b.x) >= 1024.0f || fabsf(b.y) >= 1024.0f || fabsf(b.z) >= 1024.0f || fabsf(b.w) >= 1024.0f);
 }
+// ... or every coordinate in [0, 2048] (pixel boxes up to the reference's max_coordinate): class c then occupies
+// [2049c, 2049c + 2048], again disjoint from its neighbours.  Mixing the two ranges is not safe, so each violation has
+// its own status bit and the result is refused only when both are set.
+__device__ __forceinline__ bool vx_box_in_range2(const vx_f4 &b) {
+    return b.x >= 0.0f && b.y >= 0.0f && b.z >= 0.0f && b.w >= 0.0f && b.x <= 2048.0f && b.y <= 2048.0f && b.z <= 2048.0f &&
+           b.w <= 2048.0f;
+}
+// status bits for one box (0 when it fits both ranges)
+__device__ __forceinline__ int vx_range_bits(const vx_f4 &b) {
+    return (vx_box_in_range(b) ? 0 : VX_STATUS_RANGE) | (vx_box_in_range2(b) ? 0 : VX_STATUS_RANGE2);
+}
+__device__ __forceinline__ void vx_flag_range(int bits, int *status) {       // wave-level OR, one atomic per wave
+    const bool a = __ballot(bits & VX_STATUS_RANGE) != 0ull, b2 = __ballot(bits & VX_STATUS_RANGE2) != 0ull;
+    if ((a || b2) && vx_lane() == 0) atomicOr(status, (a ? VX_STATUS_RANGE : 0) | (b2 ? VX_STATUS_RANGE2 : 0));
+}
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vx_k_nms_build_keys(const float *__restrict__ scores,
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
                 int idx = vx_key1_idx(key);
                 float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
                 vx_f4 bx = *reinterpret_cast<const vx_f4 *>(ep.boxes + ((long long)b * ep.cap + idx) * 4);
-                if (ep.guard && !vx_box_in_range(bx)) atomicOr(ep.status, VX_STATUS_RANGE);
+                if (ep.guard) { const int rb = vx_range_bits(bx); if (rb) atomicOr(ep.status, rb); }
                 bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
                 long long o = (long long)b * sp.stride + gi;
                 ep.sbox[o] = bx;
@@ -1047,17 +1062,17 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     float *sa = a.sarea + ob + lo;
     const float off = (float)(c * (VX_MAX_COORDINATE + 1));
     const bool big = len > 64 * VX_SWEEP_WT;
-    bool oob = false;
+    int oob = 0;
     for (int i = threadIdx.x; i < len; i += nt) {
         const u64 key = sk[i];
         vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
-        oob |= !vx_box_in_range(bx);
+        oob |= vx_range_bits(bx);
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         sb[i] = bx;
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
         if (big) kseg[i] = key;
     }
-    if (__ballot(oob) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_RANGE);
+    vx_flag_range(oob, a.status);
     __syncthreads();
     const vx_thr T = vx_make_thr(p.thr);
     u64 *k2 = a.keys2 + ob;
@@ -1221,16 +1236,16 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
     vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
     float ar = 0.f;
     int cl = -1;
-    bool oob = false;
+    int oob = 0;
     if (valid) {
         cl = vx_key1_cls(key);
         float off = (float)(cl * (VX_MAX_COORDINATE + 1));
         bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
-        oob = !vx_box_in_range(bx);
+        oob = vx_range_bits(bx);
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         ar = (bx.z - bx.x) * (bx.w - bx.y);
     }
-    if (p.n_classes != 1 && __ballot(oob) != 0 && lane == 0) atomicOr(a.status, VX_STATUS_RANGE);
+    if (p.n_classes != 1) vx_flag_range(oob, a.status);
     const vx_thr T = vx_make_thr(p.thr);
     u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     u64 todo = alive;
@@ -1314,18 +1329,18 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     vx_f4 *sb = a.sbox + ob;
     float *sa = a.sarea + ob;
     u64 *kg = a.keys1 + ob;
-    bool oob = false;
+    int oob = 0;
     for (int i = threadIdx.x; i < n; i += nt) {
         u64 key = sk[i];
         kg[i] = key;
         float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
         vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
-        oob |= !vx_box_in_range(bx);
+        oob |= vx_range_bits(bx);
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         sb[i] = bx;
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
     }
-    if (p.n_classes != 1 && __ballot(oob) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_RANGE);
+    if (p.n_classes != 1) vx_flag_range(oob, a.status);
     __syncthreads();
     VX_STAMP(3);
     u64 *k2 = a.keys2 + ob;
@@ -1416,6 +1431,19 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
 // ------------------------------------------------------------------------------------------------
 static inline size_t vx_align256n(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set on first use on each device.
+// The per-kernel caches are atomics (threads may enter the library concurrently; setting the attribute twice is harmless).
+#include <atomic>
+struct vx_attr_cache { std::atomic<int> done[64]; };
+static int vx_set_max_lds(vx_attr_cache &c, const void *kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
+    if (c.done[dev].load(std::memory_order_acquire)) return VX_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return VX_ERR_LAUNCH;
+    c.done[dev].store(1, std::memory_order_release);
+    return VX_OK;
+}
+
 struct vx_nms_ws {
     u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel;
     int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
@@ -1450,19 +1478,12 @@ extern "C" size_t vx_batched_nms_workspace_bytes(int B, int capacity) {
 
 static int vx_sort_launch(u64 *keys, const int *counts, int fixed_n, int B, int npad_cap, int epilogue,
                           const vx_epi_params &ep, hipStream_t st) {
-    static bool attr_set[64] = {};
+    static vx_attr_cache attr_set;
     // A/B on MI355X (FPN-SSD b64 / stress b32, both sorts): chunks of 16384 keys 0.68 / 0.67 ms, 8192 0.77 / 0.74, 4096 0.76 / 0.89
     int CH = npad_cap < VX_SORT_CHMAX ? npad_cap : VX_SORT_CHMAX;
     size_t lds = (size_t)CH * sizeof(u64);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
-    if (!attr_set[dev]) {
-        // 16384 keys x 8 B = 128 KiB of the CU's 160 KiB LDS
-        if (hipFuncSetAttribute((const void *)vx_k_sort_local, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
-            return VX_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
+    // 16384 keys x 8 B = 128 KiB of the CU's 160 KiB LDS
+    if (vx_set_max_lds(attr_set, (const void *)vx_k_sort_local, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK) return VX_ERR_LAUNCH;
     int threads = CH / 2 < 1024 ? (CH / 2 < 64 ? 64 : CH / 2) : 1024;
     vx_sort_params sp;
     sp.stride = npad_cap; sp.CH = CH; sp.k_merge = 0; sp.fixed_n = fixed_n; sp.epilogue = epilogue;
@@ -1509,15 +1530,9 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     // (sel[b] = their count, 0 = done) -- for an all-small batch its launches find nothing to do.
     const bool all_fit = npad_cap <= VX_SORT_CHMAX;
     {
-        static bool image_attr_set[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
-        if (!image_attr_set[dev]) {
-            if (hipFuncSetAttribute((const void *)vx_k_nms_image, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
-                return VX_ERR_LAUNCH;
-            image_attr_set[dev] = true;
-        }
+        static vx_attr_cache image_attr_set;
+        if (vx_set_max_lds(image_attr_set, (const void *)vx_k_nms_image, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK)
+            return VX_ERR_LAUNCH;
         vx_image_args a;
         a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.det = d_det; a.cls = (const long long *)d_cls;
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
@@ -1539,15 +1554,9 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
 
     const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
     if (partitioned) {
-        static bool part_attr_set[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VX_ERR_LAUNCH;
-        if (!part_attr_set[dev]) {
-            if (hipFuncSetAttribute((const void *)vx_k_part_sweep<VX_SORT_CHMAX, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    VX_SORT_CHMAX * (int)sizeof(u64)) != hipSuccess)
-                return VX_ERR_LAUNCH;
-            part_attr_set[dev] = true;
-        }
+        static vx_attr_cache part_attr_set;
+        if (vx_set_max_lds(part_attr_set, (const void *)vx_k_part_sweep<VX_SORT_CHMAX, 1024>, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK)
+            return VX_ERR_LAUNCH;
         vx_part_args a;
         a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.cls = (const long long *)d_cls; a.sel = w.sel;
         a.hist = w.part_hist; a.cursor = w.part_cursor; a.segstart = w.part_segstart; a.sel2 = w.sel2;

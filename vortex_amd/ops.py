@@ -4,6 +4,8 @@ Every function launches on torch's current stream, allocates its outputs/workspa
 torch (device memory plumbing) and performs NO host synchronisation; the nn.Module layer
 (preprocess.py / heads.py / postprocess.py / prior.py) does the single D2H read of the
 counts + status words where the reference's API needs Python-visible shapes."""
+import contextlib
+import functools
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -21,12 +23,29 @@ def yolo_rows(img_size: int) -> int:
     return 3 * sum((img_size // d) ** 2 for d in (32, 16, 8))
 
 
+def _on_device(fn):
+    """The library keys per-device state (LDS attributes, events, the static scratch) off HIP's CURRENT device and
+    launches on the stream it is given: when the tensors live on another device than the current one, make theirs
+    current for the duration of the call (a torch op would do the same).  One comparison when nothing has to change."""
+    @functools.wraps(fn)
+    def call(*args, **kwargs):
+        t = args[0]
+        if isinstance(t, (list, tuple)):
+            t = t[0]
+        if torch.is_tensor(t) and t.is_cuda and t.device.index not in (None, torch.cuda.current_device()):
+            with torch.cuda.device(t.device.index):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return call
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     # torch's caching allocator returns >=512-byte aligned blocks
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 # --------------------------------------------------------------------------------------- K1
+@_on_device
 def preprocess(img: torch.Tensor, mean: Sequence[float], std: Sequence[float], scaler: int = 255,
                flip: bool = False, out_size: Optional[Tuple[int, int]] = None,
                letterbox: bool = False, pad_value: int = 0) -> torch.Tensor:
@@ -45,6 +64,7 @@ def preprocess(img: torch.Tensor, mean: Sequence[float], std: Sequence[float], s
     return out
 
 
+@_on_device
 def resize_u8(img: torch.Tensor, out_size: Tuple[int, int], letterbox: bool = False, pad_value: int = 0,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """u8[B,Hs,Ws,3] -> u8[B,Hd,Wd,3] (cv2.resize INTER_LINEAR scheme); see vx_resize_u8hwc."""
@@ -63,6 +83,7 @@ def resize_u8(img: torch.Tensor, out_size: Tuple[int, int], letterbox: bool = Fa
     return out
 
 
+@_on_device
 def format_results(out_det: torch.Tensor, keep_counts: torch.Tensor, cols: Sequence[int],
                    kinds: Optional[Sequence[int]] = None, image_wh: Optional[torch.Tensor] = None) -> torch.Tensor:
     """f32[B,cap,D] + i32[B] -> f32[B*cap, len(cols)]: kept rows of all images back to back, columns
@@ -85,6 +106,7 @@ def format_results(out_det: torch.Tensor, keep_counts: torch.Tensor, cols: Seque
 
 
 # --------------------------------------------------------------------------------------- K2
+@_on_device
 def yolo_head_decode(x: torch.Tensor, anchor_wh: Sequence[float], stride: float,
                      out: Optional[torch.Tensor] = None, row_offset: int = 0) -> torch.Tensor:
     """f32[B,3(5+C),G,G] -> rows [row_offset, row_offset+3GG) of out f32[B,R,5+C]."""
@@ -130,6 +152,7 @@ class Candidates:
 
 
 # --------------------------------------------------------------------------------------- K3
+@_on_device
 def yolo_decode(pred: torch.Tensor, img_size: float, score_threshold: float, use_threshold: bool = True) -> Candidates:
     L.require_cuda(pred, "predictions")
     assert pred.dtype == torch.float32 and pred.dim() == 3
@@ -147,6 +170,7 @@ def yolo_decode(pred: torch.Tensor, img_size: float, score_threshold: float, use
 
 
 # --------------------------------------------------------------------------------------- K2+K3 fused
+@_on_device
 def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float,
                       use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False) -> Candidates:
     """heads: raw conv outputs for G = S/32, S/16, S/8 (coarse -> fine).  threshold_first: read the objectness
@@ -178,6 +202,7 @@ def yolo_fused_decode(heads: Sequence[torch.Tensor], img_size: int, score_thresh
 _ANCHOR_CACHE = {}
 
 
+@_on_device
 def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_threshold: float, iou_threshold: float,
                            use_threshold: bool = True, anchors=COCO_ANCHORS, threshold_first: bool = False,
                            top_k: Optional[int] = None, optimistic_nms: bool = False,
@@ -207,26 +232,32 @@ def yolo_fused_postprocess(heads: Sequence[torch.Tensor], img_size: int, score_t
     ws = _ws(nb, dev)
     packed = torch.empty((B * out_cap, 6), dtype=torch.float32, device=dev)
     meta = torch.empty((2 * B + 1,), dtype=torch.int32, device=dev)
+    from .postprocess import mirror_is_coherent
+    coherent = mirror_is_coherent(dev)
     host = torch.empty((2 * B + 1,), dtype=torch.int32, pin_memory=True)
     flags = int(bool(use_threshold)) | (2 if threshold_first else 0) | (4 if optimistic_nms else 0)
     if tail_stream is None:
         rc = lib.vx_yolo_fused_postprocess(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B, int(img_size), C,
                                            f18, float(score_threshold), flags, float(iou_threshold), tk,
-                                           packed.data_ptr(), meta.data_ptr(), host.data_ptr(), ws.data_ptr(), nb,
-                                           L.stream_ptr(dev))
+                                           packed.data_ptr(), meta.data_ptr(), host.data_ptr() if coherent else None,
+                                           ws.data_ptr(), nb, L.stream_ptr(dev))
     else:
         for t in (packed, meta, ws):
             t.record_stream(tail_stream)           # allocated for the current stream, last used on the tail stream
         rc = lib.vx_yolo_fused_postprocess_overlapped(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), B,
                                                       int(img_size), C, f18, float(score_threshold), flags,
                                                       float(iou_threshold), tk, packed.data_ptr(), meta.data_ptr(),
-                                                      host.data_ptr(), ws.data_ptr(), nb, L.stream_ptr(dev),
-                                                      tail_stream.cuda_stream)
+                                                      host.data_ptr() if coherent else None, ws.data_ptr(), nb,
+                                                      L.stream_ptr(dev), tail_stream.cuda_stream)
     L.check(rc, "vx_yolo_fused_postprocess")
+    if not coherent:                                   # kernel stores to pinned memory are not host-visible here: D2H copy
+        with torch.cuda.stream(tail_stream) if tail_stream is not None else contextlib.nullcontext():
+            host.copy_(meta, non_blocking=True)
     return packed, meta, host
 
 
 # --------------------------------------------------------------------------------------- K4
+@_on_device
 def prior_decode(inp: torch.Tensor, priors: torch.Tensor, n_landmarks: int, score_threshold: float,
                  use_threshold: bool = True, variances=(0.1, 0.2)) -> Candidates:
     L.require_cuda(inp, "input")
@@ -250,6 +281,7 @@ def prior_decode(inp: torch.Tensor, priors: torch.Tensor, n_landmarks: int, scor
 
 
 # --------------------------------------------------------------------------------------- K5-K7
+@_on_device
 def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor, det: torch.Tensor,
                 counts: Optional[torch.Tensor], iou_threshold: float, n_classes: int = 0,
                 top_k: Optional[int] = None, meta: Optional[torch.Tensor] = None, optimistic: bool = False):
@@ -293,6 +325,7 @@ def candidates_nms(c: Candidates, iou_threshold: float, n_classes: int = 0, top_
                        optimistic=optimistic)
 
 
+@_on_device
 def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor, meta: Optional[torch.Tensor] = None,
               host_meta: Optional[torch.Tensor] = None) -> torch.Tensor:
     """f32[B,cap,D] + i32[B] -> f32[B*cap, D] with the kept rows of all images back to back.  With `meta`
@@ -312,6 +345,7 @@ def pack_rows(out_det: torch.Tensor, keep_counts: torch.Tensor, meta: Optional[t
     return packed
 
 
+@_on_device
 def detr_decode(inputs: torch.Tensor, score_threshold: float):
     """f32[B,Q,4+n_logits] -> (rows f32[B,Q,6] compacted per image in query order, meta i32[2B+1] with the
     per-image row counts at [B:2B], same layout as the NMS paths so finish_results() applies)."""
@@ -326,6 +360,7 @@ def detr_decode(inputs: torch.Tensor, score_threshold: float):
     return out, meta
 
 
+@_on_device
 def softmax_max(logits: torch.Tensor) -> torch.Tensor:
     """f32[B,NC] logits -> f32[B,2] = (float(first arg-max of softmax), max probability) (vx_softmax_max)."""
     L.require_cuda(logits, "input")
@@ -338,6 +373,15 @@ def softmax_max(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def status_ok(status: int) -> bool:
+    """True when the status word reports nothing a caller must act on.  The two coordinate-range bits are only a
+    refusal together (VX_STATUS_RANGE / VX_STATUS_RANGE2 in include/vortex_hip.h): normalised boxes that stick out of
+    the image set RANGE2 alone, pixel boxes beyond 1024 set RANGE alone -- both are fine."""
+    both = L.VX_STATUS_RANGE | L.VX_STATUS_RANGE2
+    rest = status & ~both
+    return rest == 0 and (status & both) != both
+
+
 def raise_on_status(status: int):
     """Map device status bits to the reference's exceptions (VX_STATUS_DEFERRED is not an error: see batched_nms)."""
     if status & L.VX_STATUS_NAN:
@@ -345,7 +389,8 @@ def raise_on_status(status: int):
         raise ValueError("your predictions have nan! please check")
     if status & L.VX_STATUS_BAD_CLASS:
         raise L.VortexHipError("class index outside [0, %d): not supported by libvortex_hip" % L.VX_MAX_CLASSES)
-    if status & L.VX_STATUS_RANGE:
-        raise L.VortexHipError("class-aware NMS needs box coordinates inside (-1024, 1024) (normalised boxes): beyond "
-                               "that the reference's 2049*class shift lets classes overlap, which the per-class "
-                               "sweep of libvortex_hip does not reproduce")
+    if (status & L.VX_STATUS_RANGE) and (status & L.VX_STATUS_RANGE2):
+        raise L.VortexHipError("class-aware NMS needs every box coordinate inside (-1024, 1024) (normalised boxes) or every "
+                               "one inside [0, 2048] (pixel boxes up to the reference's max_coordinate): beyond that the "
+                               "reference's 2049*class shift lets classes overlap, which the per-class sweep of "
+                               "libvortex_hip does not reproduce")

@@ -208,7 +208,9 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         first = input[0] if isinstance(input, (list, tuple)) else input
         if first.size(0) == 0:
             return tuple()                               # the reference's loop over zero images
-        if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS):
+        # the batched launches are taken unless an exporter swapped the NMS callable (export.use_custom_ops, the
+        # reference's nms_fn hook): then the reference's per-image composition runs, so a trace records the custom op
+        if hasattr(self.decoder, "decode_batch") and isinstance(self.nms, BatchedNMS) and self.nms.nms_fn is batched_nms:
             return self.forward_async(input, score_threshold, iou_threshold).result()
         n_batch = input.size(0)
         results = []
@@ -230,6 +232,29 @@ def finish_results(packed: torch.Tensor, meta: torch.Tensor) -> Tuple[torch.Tens
     """The single D2H copy of the path: per-image keep counts + status -> tuple of f32[K'_i, D]
     (views of the packed buffer, one split call instead of B Python slices)."""
     return _split_results(packed, meta.cpu().tolist())
+
+
+_MIRROR_OK = {}
+
+
+def mirror_is_coherent(device) -> bool:
+    """The no-memcpy result path relies on a KERNEL writing torch's pinned host memory and an event making those
+    stores visible to the host: true for coherent (fine-grained) host allocations, which is what torch's pinned
+    allocator hands out on ROCm unless HIP_HOST_COHERENT=0.  Checked once per device with a known pattern; if the
+    host does not see it, callers fall back to an ordinary D2H copy."""
+    key = torch.device(device).index
+    ok = _MIRROR_OK.get(key)
+    if ok is None:
+        n = 67
+        src = torch.arange(1, n + 1, dtype=torch.int32, device=device)
+        host = torch.full((n,), -1, dtype=torch.int32, pin_memory=True)
+        rows = torch.zeros((1, 1, 1), dtype=torch.float32, device=device)
+        ops.pack_rows(rows, torch.zeros(1, dtype=torch.int32, device=device), src, host)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ev.synchronize()
+        ok = _MIRROR_OK[key] = host.tolist() == list(range(1, n + 1))
+    return ok
 
 
 _INFLIGHT = collections.deque()       # (event, pinned mirror, packed, meta) of calls whose GPU work may be pending
@@ -259,7 +284,10 @@ class PendingDetections:
     @classmethod
     def packing(cls, out_det: torch.Tensor, keep_counts: torch.Tensor, meta: torch.Tensor) -> "PendingDetections":
         """Pack the kept rows and let the pack kernel itself mirror the counts into pinned host memory
-        (vx_pack_rows meta_dst): no D2H memcpy sits between this batch's kernels and the next one's."""
+        (vx_pack_rows meta_dst): no D2H memcpy sits between this batch's kernels and the next one's.  Where kernel
+        stores to pinned memory are not visible to the host after an event (mirror_is_coherent), a D2H copy is used."""
+        if not mirror_is_coherent(meta.device):
+            return cls(ops.pack_rows(out_det, keep_counts), meta)
         host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
         return cls(ops.pack_rows(out_det, keep_counts, meta, host), meta, host)
 
