@@ -41,8 +41,8 @@ st = allw[:, :8]
 wv = allw[:, 8:].view(B, 16, 8)
 print("per-wave cycles of the column-owner sweep, image 0: [wait, apply, chain, rows, total, tests]")
 for w_ in range(16):
-    print("  wave %2d " % w_, [int(v) for v in wv[0, w_, :6]])
-print("mean over images and waves:", [int(v) for v in wv[:, :, :6].mean(dim=(0, 1))])
+    print("  wave %2d " % w_, [int(v) for v in wv[0, w_, :8]])
+print("mean over images and waves:", [int(v) for v in wv[:, :, :8].mean(dim=(0, 1))])
 d = (st[:, 1:] - st[:, :-1])
 names = ["keys", "sort1", "gather", "sweep-wave", "sweep-block", "load+sort2", "output"]
 print("candidates/img %.0f (max %d) kept/img %.0f" % (c.counts.float().mean(), int(c.counts.max()), c.keep_counts.float().mean()))

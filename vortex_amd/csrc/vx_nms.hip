@@ -597,6 +597,7 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
 // the trip with the exact routine (vx_iou_gt: bracket, then the IEEE division), as do untame lanes, tiles with a wild
 // kept box, or a threshold outside the bracket's range.
 #define VX_ASYNC_TRIP 4
+#define VX_ASYNC_MAXTILES_SP 128           // spatial sweep: segments up to 8192 boxes (fewer with fewer waves)
 
 template <int MAXTILES>
 struct vx_async_smem_t {
@@ -856,6 +857,324 @@ __device__ __forceinline__ void vx_sweep_async(vx_async_smem_t<MAXTILES> &S, voi
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Spatial sweep: the chain sweep's arithmetic with most of its IoU tests culled.  A kept box can only suppress boxes
+// it overlaps, but in score order the boxes of a tile are scattered over the whole image.  So the "column" side of
+// the sweep is re-tiled by position: the segment's boxes are counting-sorted by the Morton code of their centre cell
+// (16 x 16 cells over the segment's extent), 64 consecutive boxes form a spatial tile with a bounding box, and a kept
+// box is tested against a spatial tile only if it overlaps that bounding box (otherwise every intersection in the tile
+// is empty and the reference's predicate is false for thr > 0).  The chain side keeps the score order:
+//   wave 0           owns the chain: in phase t it applies the kept boxes of tile t to tile t+1 (score layout), resolves
+//                    tile t+1 greedily and leaves its kept boxes, compacted, in the other half of a double buffer
+//   waves 1 .. W-1   share the spatial tiles (round-robin; boxes, score ranks and bounding boxes in LDS): in phase t they
+//                    apply the kept boxes of tile t to the boxes of rank >= 64 (t+2) and clear the alive bit (LDS, indexed
+//                    by rank) of every box that dies
+// one workgroup barrier per phase.  Alive state is kept by rank, so the chain reads the word of its next tile directly.
+// Needs every box tame, a threshold inside the bracket's range and 20 bytes of scratch LDS per box (the caller falls
+// back to the chain sweep otherwise).
+#define VX_SP_CELLS 256
+
+struct vx_spatial_smem {
+    u64 alive[VX_ASYNC_MAXTILES_SP];
+    vx_f4 kb[2][64 + VX_ASYNC_TRIP];               // kept boxes of the current / next chain tile (+ null boxes for padding)
+    float kar[2][64 + VX_ASYNC_TRIP];
+    int kc[2];
+    int ktot, stop, ndone;
+    vx_f4 tb[VX_ASYNC_MAXTILES_SP];                 // bounding boxes of the spatial tiles
+    u64 rows[2][64];                                // suppression rows of the next two chain tiles
+    int hist[VX_SP_CELLS];
+    int ext[4];                                     // min x, min y, max x, max y of the box centres (order-preserving ints)
+    int untame;
+};
+
+__device__ __forceinline__ int vx_f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float vx_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__device__ __forceinline__ unsigned vx_morton4(unsigned x, unsigned y) {       // 4 + 4 bits interleaved
+    x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
+    y = (y | (y << 2)) & 0x33u; y = (y | (y << 1)) & 0x55u;
+    return x | (y << 1);
+}
+
+// one trip: lanes of `act` that one of the four wave-uniform boxes K suppresses (tame boxes, threshold in range)
+__device__ __forceinline__ u64 vx_trip_test(const vx_f4 *K, const vx_v4 &ka, const vx_f4 &bx, float a, u64 act, const vx_thr &T) {
+    float m = vx_async_cand(K[0], ka.x, bx, a, T.lo);
+    m = vx_vmax<false>(m, vx_async_cand(K[1], ka.y, bx, a, T.lo));
+    m = vx_vmax<false>(m, vx_async_cand(K[2], ka.z, bx, a, T.lo));
+    m = vx_vmax<false>(m, vx_async_cand(K[3], ka.w, bx, a, T.lo));
+    const u64 slow = __ballot(!(m < 0.0f)) & act;
+    if (!slow) return 0ull;
+    const float kaq[4] = {ka.x, ka.y, ka.z, ka.w};
+    bool sup = false, und = false;
+    float in_[4], un_[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        vx_iou_parts<false>(K[q].x, K[q].y, K[q].z, K[q].w, kaq[q], bx.x, bx.y, bx.z, bx.w, a, in_[q], un_[q]);
+        sup = vx_iou_bracket(in_[q], un_[q], T, und) || sup;
+    }
+    if (__ballot(und && ((slow >> vx_lane()) & 1ull)) != 0ull) {
+        sup = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sup = sup || (in_[q] / un_[q]) > T.thr;
+    }
+    return __ballot(sup) & slow;
+}
+
+// lds: scratch LDS of lds_bytes (16-byte aligned) for the spatially ordered copy of the segment (20 bytes per box).
+// Returns false (nothing done) when the segment does not qualify; else ends synchronised with the kept masks in
+// S.alive[0 .. S.ndone).
+__device__ __noinline__ bool vx_sweep_spatial(vx_spatial_smem &S, void *lds, size_t lds_bytes, const vx_f4 *__restrict__ sbox,
+                                              int n, const vx_thr T /* by value: the routine is a real call */, int top_k,
+                                              unsigned long long *iou_count, u64 *dbg = nullptr) {
+    const int lane = vx_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6, nt = blockDim.x;
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int NT = (n + 63) >> 6;
+    const u64 c00 = dbg ? clock64() : 0;
+    u64 c_work = 0, c_wait = 0, c_setup = 0, c_rows = 0, cs = 0, n_vis = 0, n_trip = 0;
+    if (!T.fast || W < 2 || (64 % W) != 0 || NT > 32 * (W - 1) || NT > VX_ASYNC_MAXTILES_SP || (size_t)NT * 64 * 20 > lds_bytes)
+        return false;
+    vx_f4 *lbox = reinterpret_cast<vx_f4 *>(lds);                       // [NT*64] boxes in spatial order
+    int *lrank = reinterpret_cast<int *>(lbox + NT * 64);               // [NT*64] their score ranks (-1: padding)
+    __syncthreads();
+    for (int i = threadIdx.x; i < VX_SP_CELLS; i += nt) S.hist[i] = 0;
+    for (int i = threadIdx.x; i < NT; i += nt) {
+        const int rem = n - i * 64;
+        S.alive[i] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    }
+    for (int i = n + threadIdx.x; i < NT * 64; i += nt) lrank[i] = -1;
+    if (threadIdx.x == 0) {
+        S.ext[0] = S.ext[1] = 0x7fffffff; S.ext[2] = S.ext[3] = (int)0x80000000;
+        S.untame = 0; S.ktot = 0; S.stop = 0; S.ndone = 0; S.kc[0] = S.kc[1] = 0;
+    }
+    if (threadIdx.x < 2 * VX_ASYNC_TRIP) {          // the padding boxes of both buffers meet nothing
+        const vx_f4 far = {1e30f, 1e30f, 1e30f, 1e30f};
+        S.kb[threadIdx.x >> 2][64 + (threadIdx.x & 3)] = far;
+        S.kar[threadIdx.x >> 2][64 + (threadIdx.x & 3)] = 0.0f;
+    }
+    __syncthreads();
+    // extent of the centres, tameness
+    {
+        float mnx = 3e38f, mny = 3e38f, mxx = -3e38f, mxy = -3e38f;
+        bool bad = false;
+        for (int i = threadIdx.x; i < n; i += nt) {
+            const vx_f4 b = sbox[i];
+            bad |= !vx_tame(b, (b.z - b.x) * (b.w - b.y));
+            const float cx = b.x + b.z, cy = b.y + b.w;
+            mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx); mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, d)); mny = fminf(mny, __shfl_xor(mny, d));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, d)); mxy = fmaxf(mxy, __shfl_xor(mxy, d));
+        }
+        if (lane == 0) {
+            atomicMin(&S.ext[0], vx_f2ord(mnx)); atomicMin(&S.ext[1], vx_f2ord(mny));
+            atomicMax(&S.ext[2], vx_f2ord(mxx)); atomicMax(&S.ext[3], vx_f2ord(mxy));
+        }
+        if (__ballot(bad) != 0ull && lane == 0) S.untame = 1;
+    }
+    __syncthreads();
+    if (S.untame) { __syncthreads(); return false; }
+    const float ex0 = vx_ord2f(S.ext[0]), ey0 = vx_ord2f(S.ext[1]);
+    const float sx = 16.0f / fmaxf(vx_ord2f(S.ext[2]) - ex0, 1e-30f), sy = 16.0f / fmaxf(vx_ord2f(S.ext[3]) - ey0, 1e-30f);
+    auto cell_of = [&](const vx_f4 &b) __attribute__((always_inline)) -> int {
+        const int cx = min(15, max(0, (int)((b.x + b.z - ex0) * sx))), cy = min(15, max(0, (int)((b.y + b.w - ey0) * sy)));
+        return (int)vx_morton4((unsigned)cx, (unsigned)cy);
+    };
+    for (int i = threadIdx.x; i < n; i += nt) atomicAdd(&S.hist[cell_of(sbox[i])], 1);
+    __syncthreads();
+    if (w == 0) {                                    // exclusive scan of the 256 cell counts: 4 per lane
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = S.hist[lane * 4 + q]; tot += v[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { S.hist[lane * 4 + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += nt) {      // scatter into cell order (any order inside a cell)
+        const vx_f4 b = sbox[i];
+        const int pos = atomicAdd(&S.hist[cell_of(b)], 1);
+        lbox[pos] = b;
+        lrank[pos] = i;
+    }
+    __syncthreads();
+    for (int v = w; v < NT; v += W) {                // bounding boxes of the spatial tiles
+        vx_f4 q = {3e38f, 3e38f, -3e38f, -3e38f};
+        if (lrank[v * 64 + lane] >= 0) q = lbox[v * 64 + lane];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            q.x = fminf(q.x, __shfl_xor(q.x, d)); q.y = fminf(q.y, __shfl_xor(q.y, d));
+            q.z = fmaxf(q.z, __shfl_xor(q.z, d)); q.w = fmaxf(q.w, __shfl_xor(q.w, d));
+        }
+        if (lane == 0) S.tb[v] = q;
+    }
+    unsigned long long tests = 0ull;
+    unsigned gone = 0u;                             // bit s: this wave's s-th spatial tile has nobody left behind the chain
+    // chain tiles in score layout: cb = the tile wave 0 resolves next, nb = the tile after it (whose suppression rows
+    // every wave helps to build one phase ahead: row i = later boxes of the tile that box i suppresses, by wave i % W)
+    vx_f4 cb = {0.f, 0.f, 0.f, 0.f}, nb = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int t) __attribute__((always_inline)) -> vx_f4 {
+        const int o = t * 64 + lane;
+        vx_f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (t < NT && o < n) b = sbox[o];
+        return b;
+    };
+    auto build_rows = [&](int t, const vx_f4 &tb_) __attribute__((always_inline)) {
+        if (t >= NT) return;
+        const float ta = (tb_.z - tb_.x) * (tb_.w - tb_.y);
+        const u64 snap = vx_uniform64(S.alive[t]);   // a superset of the tile's alive mask when it is resolved
+        u64 mine = 0ull;                             // rows i = w, w + W, ... (W divides 64)
+        for (int i = w; i < 64; i += W) mine |= snap & (1ull << i);
+        while (mine) {
+            const int i = __builtin_ctzll(mine);
+            mine &= mine - 1ull;
+            const u64 am = snap & ~((2ull << i) - 1ull);
+            u64 m = 0ull;
+            if (am) {
+                vx_f4 K;
+                K.x = vx_bcast(tb_.x, i); K.y = vx_bcast(tb_.y, i); K.z = vx_bcast(tb_.z, i); K.w = vx_bcast(tb_.w, i);
+                tests += __popcll(am);
+                m = vx_async_test(K, vx_bcast(ta, i), false, tb_, ta, 0ull, am, T);
+            }
+            if (lane == 0) S.rows[t & 1][i] = m;
+        }
+    };
+    // wave 0: tile t (boxes in cb), every earlier kept box applied (mask a): bit walk over the prebuilt rows, kept boxes
+    // compacted into buffer t & 1
+    auto resolve = [&](int t, u64 a) __attribute__((always_inline)) {
+        const float ca = (cb.z - cb.x) * (cb.w - cb.y);
+        const u64 row = S.rows[t & 1][lane];
+        const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
+        u64 todo = a;
+        while (todo) {
+            const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            const u64 ri = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                           (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
+            a &= ~ri;
+            todo = a & ~((2ull << i) - 1ull);
+        }
+        int ktot = S.ktot, nk = __popcll(a);
+        bool stop = t + 1 >= NT;
+        if (top_k > 0 && ktot + nk >= top_k) {       // only the segment's first top_k kept boxes matter
+            int excess = ktot + nk - top_k;
+            while (excess-- > 0) a &= ~(1ull << (63 - __builtin_clzll(a)));
+            nk = top_k - ktot;
+            stop = true;
+        }
+        const int buf = t & 1;
+        if ((a >> lane) & 1ull) {
+            const int pos = vx_mbcnt(a);
+            S.kb[buf][pos] = cb;
+            S.kar[buf][pos] = ca;
+        }
+        if (lane < VX_ASYNC_TRIP && nk + lane < 64) {    // null boxes behind the kept ones: the chain's apply loop reads whole trips
+            const vx_f4 far = {1e30f, 1e30f, 1e30f, 1e30f};
+            S.kb[buf][nk + lane] = far;
+            S.kar[buf][nk + lane] = 0.0f;
+        }
+        if (lane == 0) { S.alive[t] = a; S.kc[buf] = nk; S.ktot = ktot + nk; S.ndone = t + 1; if (stop) S.stop = 1; }
+    };
+    cb = load_tile(0);
+    nb = load_tile(1);
+    build_rows(0, cb);
+    build_rows(1, nb);
+    __syncthreads();
+    if (w == 0) resolve(0, vx_uniform64(S.alive[0]));
+    cb = nb;
+    nb = load_tile(2);
+    __syncthreads();
+    if (dbg) { cs = clock64(); c_setup = cs - c00; }
+    for (int t = 0; t + 1 < NT; ++t) {
+        if (S.stop) break;                           // uniform: written before the last barrier
+        const int buf = t & 1;
+        const int kc = __builtin_amdgcn_readfirstlane(S.kc[buf]);
+        // here: cb = tile t+1, nb = tile t+2
+        if (w == 0) {
+            u64 a = vx_uniform64(S.alive[t + 1]);
+            const float ca = (cb.z - cb.x) * (cb.w - cb.y);
+            const u64 unt0 = 0ull;
+            tests += (unsigned long long)kc * __popcll(a);
+            if (kc > 0 && a) vx_async_apply<1>(S.kb[buf], S.kar[buf], kc, false, &cb, &ca, &a, &unt0, T);
+            resolve(t + 1, a);
+        } else if (kc > 0) {
+            const int thr_rank = 64 * (t + 2);
+            vx_f4 Kl = {0.f, 0.f, 0.f, 0.f};
+            if (lane < kc) Kl = S.kb[buf][lane];
+            // this wave's spatial tiles v = (w-1) + s (W-1); the next tile's bounding box is in flight during a visit
+            int v = w - 1;
+            vx_f4 tbb = S.tb[min(v, NT - 1)];
+#pragma nounroll
+            for (int s = 0; v < NT; ++s, v += W - 1) {
+                const vx_f4 cur = tbb;
+                tbb = S.tb[min(v + W - 1, NT - 1)];
+                if ((gone >> s) & 1u) continue;
+                // kept boxes that reach into the tile's bounding box (lane = kept box)
+                u64 m = __ballot(lane < kc && !(Kl.z <= cur.x || Kl.x >= cur.z || Kl.w <= cur.y || Kl.y >= cur.w));
+                if (m == 0ull) continue;
+                const int r = lrank[v * 64 + lane];
+                const vx_f4 bx = lbox[v * 64 + lane];
+                const u64 aw = S.alive[max(r, 0) >> 6];
+                u64 act = __ballot(r >= thr_rank && ((aw >> (r & 63)) & 1ull));
+                if (act == 0ull) { gone |= 1u << s; continue; }      // nobody left behind the chain, now or later
+                const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+                u64 dead = 0ull;
+                if (dbg) ++n_vis;
+                while (m != 0ull && act != 0ull) {
+                    if (dbg) ++n_trip;
+                    int idx[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        idx[q] = 64 + q;                             // a null box unless another kept box is left
+                        if (m != 0ull) { idx[q] = __builtin_ctzll(m); m &= m - 1ull; }
+                    }
+                    vx_f4 K[4];
+                    vx_v4 ka;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) K[q] = S.kb[buf][idx[q]];
+                    ka.x = S.kar[buf][idx[0]]; ka.y = S.kar[buf][idx[1]]; ka.z = S.kar[buf][idx[2]]; ka.w = S.kar[buf][idx[3]];
+                    tests += 4ull * __popcll(act);
+                    const u64 sup = vx_trip_test(K, ka, bx, ar, act, T);
+                    act &= ~sup;
+                    dead |= sup;
+                }
+                if ((dead >> lane) & 1ull) atomicAnd(&S.alive[r >> 6], ~(1ull << (r & 63)));
+            }
+        }
+        if (dbg) { u64 now = clock64(); c_work += now - cs; cs = now; }
+        build_rows(t + 2, nb);                       // for the phase after the next one's resolve
+        cb = nb;
+        nb = load_tile(t + 3);
+        if (dbg) { u64 now = clock64(); c_rows += now - cs; cs = now; }
+        __syncthreads();
+        if (dbg) { u64 now = clock64(); c_wait += now - cs; cs = now; }
+    }
+    if (iou_count && lane == 0 && tests) atomicAdd(iou_count, tests);
+    if (dbg && lane == 0 && w < 16) {
+        u64 *d = dbg + w * 8;
+        d[0] = c_wait; d[1] = c_work; d[2] = c_setup; d[3] = c_rows; d[4] = clock64() - c00; d[5] = tests; d[6] = n_vis; d[7] = n_trip;
+    }
+    __syncthreads();
+    return true;
+}
+
+// kept masks of vx_sweep_spatial -> keys2
+__device__ __forceinline__ void vx_spatial_emit(const vx_spatial_smem &S, const u64 *__restrict__ keys,
+                                                u64 *__restrict__ keys2, int *count2) {
+    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ND = S.ndone;
+    for (int u = wave; u < ND; u += nw) {
+        const u64 m = S.alive[u];
+        const bool mine = (m >> lane) & 1ull;
+        const u64 key = mine ? keys[u * 64 + lane] : 0ull;
+        vx_emit_kept(m, mine, key, keys2, count2);
+    }
+    __syncthreads();
+}
+
 // kept masks of vx_sweep_async -> keys2 (keys = the segment's sorted key1s in global memory)
 template <int MAXTILES>
 __device__ __forceinline__ void vx_async_emit(const vx_async_smem_t<MAXTILES> &S, const u64 *__restrict__ keys,
@@ -1042,6 +1361,7 @@ template <int LDS_KEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
+    __shared__ vx_spatial_smem SP;
     const int b = blockIdx.y, c = blockIdx.x;
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
     const int lo = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
@@ -1079,6 +1399,8 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     int *c2 = a.count2 + b;
     if (!big) {
         if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count);
+    } else if (vx_sweep_spatial(SP, sk, (size_t)(LDS_KEYS > VX_PART_SMALL ? VX_SORT_CHMAX * 8 : VX_PART_SMALL * 20), sb, len, T, p.top_k, a.iou_count)) {
+        vx_spatial_emit(SP, kseg, k2, c2);
     } else {
         vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
         vx_async_emit(A, kseg, k2, c2);
@@ -1196,6 +1518,7 @@ struct vx_image_args {
     int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
     int *sel;         // optional [B]: out, n if the image has more than n_max candidates (left to the multi-kernel path) else 0
     int n_max;
+    size_t lds_bytes; // dynamic LDS of the launch
     int defer;        // != 0: such images are only reported (VX_STATUS_DEFERRED, keep_count 0), nobody finishes them
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
 };
@@ -1280,6 +1603,7 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
+    __shared__ vx_spatial_smem SP;
     __shared__ int s_big[VX_SWEEP_MAXBIG][2];
     __shared__ int s_nbig, s_count2, s_nseg;
     __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
@@ -1397,8 +1721,12 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
     for (int q = 0; q < nbig; ++q) {
         const int lo = s_big[q][0], len = s_big[q][1];
-        vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
-        vx_async_emit(A, kg + lo, k2, &s_count2);
+        if (vx_sweep_spatial(SP, sk, a.lds_bytes, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr)) {
+            vx_spatial_emit(SP, kg + lo, k2, &s_count2);
+        } else {
+            vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
+            vx_async_emit(A, kg + lo, k2, &s_count2);
+        }
     }
     __syncthreads();
     VX_STAMP(5);
@@ -1545,6 +1873,13 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         // the same LDS holds the sort keys and later the kept-box ring of the column-owner sweep
         size_t lds = (size_t)lds_keys * sizeof(u64);
         if (lds < vx_async_ring_bytes(threads / 64)) lds = vx_async_ring_bytes(threads / 64);
+        // the spatial sweep of a large class segment wants 20 bytes per box
+        {
+            size_t want = (size_t)((capacity + 63) / 64) * 64 * 20;
+            if (want > (size_t)VX_SORT_CHMAX * sizeof(u64)) want = (size_t)VX_SORT_CHMAX * sizeof(u64);
+            if (lds < want) lds = want;
+        }
+        a.lds_bytes = lds;
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
         hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), lds, st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
@@ -1570,8 +1905,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         hipLaunchKernelGGL(vx_k_part_scatter, tiles, dim3(1024), 0, st, a);
         vx_prof_end(VX_PROF_NMS_KEYS, st);
         vx_prof_begin(VX_PROF_SWEEP, st);
-        // dynamic LDS: the segment's keys while sorting, then the kept-box ring of the column-owner sweep (20 KiB at 8 waves)
-        hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), vx_async_ring_bytes(8), st, a);
+        // dynamic LDS: the segment's keys while sorting, then the sweep's scratch (spatial copy of the segment: 20 B per box)
+        hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), VX_PART_SMALL * 20, st, a);
         hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(n_classes, B), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
         vx_prof_end(VX_PROF_SWEEP, st);
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
