@@ -210,6 +210,42 @@ def test_batched_nms_vs_oracle(K, C, thr, seed):
                                   scores=scores.to(DEV), iou_threshold=torch.tensor([thr])), det[:, ref[:100]])
 
 
+@pytest.mark.parametrize("top_k", [None, 5000, 300])
+def test_batched_nms_declared_classes_multi_kernel_paths(top_k):
+    """A batch beyond the single-launch kernel with the class count declared (what the post-process modules do):
+    image 0 takes the class-partitioned path (20 balanced classes), image 1 has one class of > 16384 boxes (general
+    path: global sort + chain sweep), image 2 is small (single-launch kernel), image 3 is empty.  Without top_k and
+    with a top_k beyond the radix select the kept keys are merged from ordered per-class runs (vx_k_runs_merge);
+    top_k = 300 takes the select.  Every image must equal the oracle on its own candidates."""
+    from vortex_amd import ops
+    K, C = 30000, 20
+    boxes = torch.zeros(4, K, 4)
+    scores = torch.zeros(4, K)
+    cls = torch.zeros(4, K, dtype=torch.int64)
+    counts = torch.tensor([K, 24000, 900, 0], dtype=torch.int32)
+    b0, s0, c0 = O.synth_stress_boxes(K, C, 41)
+    boxes[0], scores[0], cls[0] = b0, s0, c0
+    b1, s1, c1 = O.synth_stress_boxes(24000, C, 42)
+    c1 = torch.where(torch.arange(24000) % 10 < 8, torch.full_like(c1, 7), c1)          # ~19 700 boxes of class 7
+    boxes[1, :24000], scores[1, :24000], cls[1, :24000] = b1, s1, c1
+    b2, s2, c2 = O.synth_stress_boxes(900, C, 43)
+    boxes[2, :900], scores[2, :900], cls[2, :900] = b2, s2, c2
+    scores[0, 100:140] = scores[0, 99]                                                   # score ties across classes: index order decides
+    det = torch.cat((boxes, scores[..., None], cls[..., None].float()), 2)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV),
+                                                             counts.to(DEV), 0.45, n_classes=C, top_k=top_k)
+    assert ops.status_ok(int(status.item()))
+    for b in range(4):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([0.45]))
+        if top_k:
+            ref = ref[:top_k]
+        kc = int(keep_counts[b].item())
+        assert kc == ref.numel(), (b, kc, ref.numel())
+        same(keep_idx[b, :kc], ref)
+        same(out_det[b, :kc], det[b, ref])
+
+
 @pytest.mark.parametrize("base", [0.5, 0.25, 1.0 / 3.0, 0.2, 2.0 / 7.0, 1e-7, 0.999999])
 def test_batched_nms_iou_exactly_at_threshold(base):
     """Integer-grid boxes: intersections and unions are exact small integers, so many pairs have an IoU whose

@@ -27,6 +27,7 @@
 #define VX_STAMP_WORDS (8 + 16 * 8)     // per image: 8 phase stamps of vx_k_nms_image + 8 words per wave of its last column-owner sweep
 #define VX_SWEEP_WT 4                 // wave routine: segments up to 64*WT boxes
 #define VX_ALIVE_WORDS 2048           // block routine: segments up to 64*2048 = 131072 boxes
+#define VX_PART_MAX_CLASSES 256       // class-partitioned path: most classes it takes
 #define VX_SWEEP_MAXBIG 128           // large segments queued per workgroup (>= classes per workgroup)
 
 struct vx_nms_params {
@@ -458,6 +459,42 @@ __device__ __forceinline__ void vx_emit_kept(u64 m, bool mine, u64 key1, u64 *__
     if (mine) keys2[base + vx_mbcnt(m)] = vx_key2_from_key1(key1);
 }
 
+// Ordered emission (class-partitioned path with a run merge instead of a second sort): the kept keys of a segment go
+// to keys2[at + rank inside the kept mask], at = the kept boxes of the segment's earlier tiles, so that the
+// segment's kept keys form one ascending run.
+__device__ __forceinline__ void vx_emit_kept_at(u64 m, bool mine, u64 key1, u64 *__restrict__ keys2, int at) {
+    if (mine) keys2[at + vx_mbcnt(m)] = vx_key2_from_key1(key1);
+}
+
+__device__ __forceinline__ int vx_wave_sum_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// kept masks alive[0..ND) of a workgroup sweep -> keys2: through the image's counter (any order), or, with kcount,
+// as one ordered run at keys2[0..*kcount)
+__device__ __forceinline__ void vx_masks_emit(const u64 *alive, int ND, const u64 *__restrict__ keys,
+                                              u64 *__restrict__ keys2, int *count2, int *kcount) {
+    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (kcount && ND == 0 && threadIdx.x == 0) *kcount = 0;
+    for (int u = wave; u < ND; u += nw) {
+        const u64 m = alive[u];
+        const bool mine = (m >> lane) & 1ull;
+        const u64 key = mine ? keys[u * 64 + lane] : 0ull;
+        if (kcount) {
+            int s = 0;
+            for (int q = lane; q < u; q += 64) s += __popcll(alive[q]);
+            s = vx_wave_sum_i(s);
+            vx_emit_kept_at(m, mine, key, keys2, s);
+            if (u == ND - 1 && lane == 0) *kcount = s + __popcll(m);
+        } else {
+            vx_emit_kept(m, mine, key, keys2, count2);
+        }
+    }
+    __syncthreads();
+}
+
 // pair index p = j(j-1)/2 + i (0 <= i < j < 64)  ->  (j << 6) | i, for all 2016 pairs of a 64-box tile
 #define VX_NPAIRS64 2016
 __device__ __forceinline__ void vx_build_pair_lut(unsigned short *lut) {
@@ -523,7 +560,7 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
 __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
                                               const u64 *__restrict__ keys1, int lo, int n, const vx_thr &thr,
                                               u64 *__restrict__ keys2, int *__restrict__ count2,
-                                              unsigned long long *iou_count = nullptr) {
+                                              unsigned long long *iou_count = nullptr, int *kcount = nullptr) {
     const int lane = vx_lane();
     unsigned long long tests = 0ull;
     float x1[VX_SWEEP_WT], y1[VX_SWEEP_WT], x2[VX_SWEEP_WT], y2[VX_SWEEP_WT], ar[VX_SWEEP_WT];
@@ -564,14 +601,17 @@ __device__ __forceinline__ void vx_sweep_wave(const vx_f4 *__restrict__ sbox, co
             }
         }
     }
+    int at = 0;
 #pragma unroll
     for (int u = 0; u < VX_SWEEP_WT; ++u) {
         if (u * 64 < n) {
             u64 m = __ballot(alive[u]);
             u64 key = alive[u] ? keys1[lo + u * 64 + lane] : 0ull;
-            vx_emit_kept(m, alive[u], key, keys2, count2);
+            if (kcount) { vx_emit_kept_at(m, alive[u], key, keys2, at); at += __popcll(m); }
+            else vx_emit_kept(m, alive[u], key, keys2, count2);
         }
     }
+    if (kcount && lane == 0) *kcount = at;
     if (iou_count && tests && lane == 0) atomicAdd(iou_count, tests);
 }
 
@@ -1163,46 +1203,33 @@ __device__ __noinline__ bool vx_sweep_spatial(vx_spatial_smem &S, void *lds, siz
 
 // kept masks of vx_sweep_spatial -> keys2
 __device__ __forceinline__ void vx_spatial_emit(const vx_spatial_smem &S, const u64 *__restrict__ keys,
-                                                u64 *__restrict__ keys2, int *count2) {
-    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int ND = S.ndone;
-    for (int u = wave; u < ND; u += nw) {
-        const u64 m = S.alive[u];
-        const bool mine = (m >> lane) & 1ull;
-        const u64 key = mine ? keys[u * 64 + lane] : 0ull;
-        vx_emit_kept(m, mine, key, keys2, count2);
-    }
-    __syncthreads();
+                                                u64 *__restrict__ keys2, int *count2, int *kcount = nullptr) {
+    vx_masks_emit(S.alive, S.ndone, keys, keys2, count2, kcount);
 }
 
 // kept masks of vx_sweep_async -> keys2 (keys = the segment's sorted key1s in global memory)
 template <int MAXTILES>
 __device__ __forceinline__ void vx_async_emit(const vx_async_smem_t<MAXTILES> &S, const u64 *__restrict__ keys,
-                                              u64 *__restrict__ keys2, int *count2) {
-    const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int ND = S.ndone;
-    for (int u = wave; u < ND; u += nw) {
-        const u64 m = S.alive[u];
-        const bool mine = (m >> lane) & 1ull;
-        const u64 key = mine ? keys[u * 64 + lane] : 0ull;
-        vx_emit_kept(m, mine, key, keys2, count2);
-    }
-    __syncthreads();
+                                              u64 *__restrict__ keys2, int *count2, int *kcount = nullptr) {
+    vx_masks_emit(S.alive, S.ndone, keys, keys2, count2, kcount);
 }
 
 __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
                                                       const float *__restrict__ sarea,
                                                       const int *__restrict__ counts, vx_nms_params p,
                                                       u64 *__restrict__ keys2, int *__restrict__ count2,
-                                                      unsigned long long *iou_count) {
+                                                      unsigned long long *iou_count, int *__restrict__ kept_runs) {
+    // kept_runs != nullptr (run merge, see vx_k_runs_merge): the kept keys of class c go in order to
+    // keys2[segment start + rank] and their number to kept_runs[b][c]
     __shared__ vx_async_smem_big S;
     __shared__ __attribute__((aligned(16))) unsigned char s_ring[(2 * 16 * 64 + 8) * 20];      // vx_async_ring_bytes(16 waves)
-    __shared__ int s_big[VX_SWEEP_MAXBIG][2];
+    __shared__ int s_big[VX_SWEEP_MAXBIG][3];
     __shared__ int s_nbig;
     const int b = blockIdx.y;
     const int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
     if (n == 0) return;
     const long long ob = (long long)b * p.npad_cap;
+    int *kr = kept_runs ? kept_runs + b * VX_PART_MAX_CLASSES : nullptr;
     const u64 *k1 = keys1 + ob;
     const vx_f4 *sb = sbox + ob;
     const float *sa = sarea + ob;
@@ -1224,10 +1251,10 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
         int hi = c + 1 < VX_MAX_CLASSES ? vx_lower_bound_wave(k1, n, (u64)(c + 1) << 52) : n;
         int len = hi - lo;
         if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, k1, lo, len, T, k2, c2, iou_count);
+            vx_sweep_wave(sb, sa, k1, lo, len, T, kr ? k2 + lo : k2, c2, iou_count, kr ? kr + c : nullptr);
         } else if (vx_lane() == 0) {
             int q = atomicAdd(&s_nbig, 1);
-            s_big[q][0] = lo; s_big[q][1] = len;
+            s_big[q][0] = lo; s_big[q][1] = len; s_big[q][2] = c;
         }
     }
     __syncthreads();
@@ -1235,7 +1262,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
     const int nbig = s_nbig;
     for (int q = 0; q < nbig; ++q) {
         vx_sweep_async(S, s_ring, sb + s_big[q][0], s_big[q][1], T, p.top_k, iou_count);
-        vx_async_emit(S, k1 + s_big[q][0], k2, c2);
+        vx_async_emit(S, k1 + s_big[q][0], kr ? k2 + s_big[q][0] : k2, c2, kr ? kr + s_big[q][2] : nullptr);
     }
 }
 
@@ -1252,7 +1279,6 @@ __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ k
 //                       larger ones up to VX_SORT_CHMAX (128 KiB).
 // An image with a segment beyond VX_SORT_CHMAX is left to the general path (sel2[b] = its count).
 #define VX_PART_MIN_CLASSES 4
-#define VX_PART_MAX_CLASSES 256
 #define VX_PART_SMALL 2048
 #define VX_PART_TILE 4096
 
@@ -1269,6 +1295,8 @@ struct vx_part_args {
     float *sarea;
     int *count2, *status;
     unsigned long long *iou_count;   // optional: useful lane-level IoU tests executed (measurement only)
+    int ordered;           // 1: the kept keys of class c go, in order, to keys2[segstart[c]..) and their number to
+                           //    hist[b][c] (the run merge below takes them from there); 0: keys2 through count2
 };
 
 __device__ __forceinline__ int vx_part_class(long long c, int n_classes, bool &bad) {
@@ -1395,15 +1423,121 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     vx_flag_range(oob, a.status);
     __syncthreads();
     const vx_thr T = vx_make_thr(p.thr);
-    u64 *k2 = a.keys2 + ob;
+    u64 *k2 = a.keys2 + ob + (a.ordered ? lo : 0);
     int *c2 = a.count2 + b;
+    int *kc = a.ordered ? a.hist + b * VX_PART_MAX_CLASSES + c : nullptr;     // the histogram has been consumed
     if (!big) {
-        if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count);
+        if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count, kc);
     } else if (vx_sweep_spatial(SP, sk, (size_t)(LDS_KEYS > VX_PART_SMALL ? VX_SORT_CHMAX * 8 : VX_PART_SMALL * 20), sb, len, T, p.top_k, a.iou_count)) {
-        vx_spatial_emit(SP, kseg, k2, c2);
+        vx_spatial_emit(SP, kseg, k2, c2, kc);
     } else {
         vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
-        vx_async_emit(A, kseg, k2, c2);
+        vx_async_emit(A, kseg, k2, c2, kc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Run merge (class-partitioned path, ordered emission): the kept keys of an image are n_classes ascending runs; a
+// second sort of all of them (log^2 passes) is replaced by  compact (runs made adjacent, boundaries R[b][0..NC])  and
+// ceil(log2 NC) merge rounds.  In round g (1, 2, 4, ...) the runs [2jg, (2j+1)g) and [(2j+1)g, (2j+2)g) are merged:
+// every key finds its place by one binary search in the sibling run (keys are unique: the index is part of the key).
+#define VX_RUNS_TILE 1024
+
+__device__ __forceinline__ bool vx_runs_load(const vx_part_args &a, const int *__restrict__ R, int b, int *s_R) {
+    if (a.sel[b] == 0) return false;                 // finished by vx_k_nms_image
+    for (int c = threadIdx.x; c <= a.p.n_classes; c += blockDim.x) s_R[c] = R[b * (VX_PART_MAX_CLASSES + 1) + c];
+    __syncthreads();
+    return true;
+}
+
+// largest r in [0, NC) with s_R[r] <= o (o < s_R[NC]): the run that holds position o
+__device__ __forceinline__ int vx_runs_find(const int *s_R, int NC, int o) {
+    int lo = 0, hi = NC;                             // invariant: s_R[lo] <= o < s_R[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (s_R[mid] <= o) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void vx_k_runs_compact(vx_part_args a, u64 *__restrict__ dst, int *__restrict__ R) {
+    __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
+    const int b = blockIdx.y;
+    if (a.sel[b] == 0) return;
+    const int NC = a.p.n_classes;
+    if (threadIdx.x < 64) {                          // exclusive scan of the kept counts (<= 256: 4 per lane)
+        const int lane = threadIdx.x;
+        const int *h = a.hist + b * VX_PART_MAX_CLASSES;
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int c = lane * 4 + q; v[q] = c < NC ? h[c] : 0; tot += v[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int c = lane * 4 + q; if (c <= NC) s_R[c] = run; run += v[q]; }
+        if (lane == 63) s_R[NC] = incl;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c <= NC; c += blockDim.x) R[b * (VX_PART_MAX_CLASSES + 1) + c] = s_R[c];
+    const int total = s_R[NC];
+    const long long ob = (long long)b * a.p.npad_cap;
+    const int *seg = a.segstart + b * (VX_PART_MAX_CLASSES + 1);
+    const int o1 = min(total, (int)(blockIdx.x + 1) * VX_RUNS_TILE);
+    for (int o = blockIdx.x * VX_RUNS_TILE + threadIdx.x; o < o1; o += blockDim.x) {
+        const int c = vx_runs_find(s_R, NC, o);
+        dst[ob + o] = a.keys2[ob + seg[c] + (o - s_R[c])];
+    }
+}
+
+// one key per thread: the binary search is a chain of dependent L2 reads, so the launch wants as many of them in
+// flight as it can get.  LAST: the final round writes the outputs (the second sort's epilogue) instead of the keys.
+#define VX_MERGE_TILE 256
+template <bool LAST>
+__global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a, const u64 *__restrict__ src,
+                                                                u64 *__restrict__ dst, const int *__restrict__ R, int g,
+                                                                vx_epi_params ep) {
+    __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
+    const int b = blockIdx.y;
+    if (!vx_runs_load(a, R, b, s_R)) return;
+    const int NC = a.p.n_classes;
+    const int total = s_R[NC];
+    int nk = total;
+    if (LAST) {
+        if (ep.top_k > 0) nk = min(nk, ep.top_k);
+        nk = min(nk, ep.out_cap);
+        if (blockIdx.x == 0 && threadIdx.x == 0) ep.keep_counts[b] = nk;
+    }
+    const int o = blockIdx.x * VX_MERGE_TILE + threadIdx.x;
+    if (o >= total) return;
+    const long long ob = (long long)b * a.p.npad_cap;
+    const u64 *s = src + ob;
+    const int r = vx_runs_find(s_R, NC, o);
+    const int G = (r / g) & ~1;                      // groups of g runs; groups G and G + 1 are merged
+    const int a0 = s_R[min(G * g, NC)], m0 = s_R[min((G + 1) * g, NC)], b1 = s_R[min((G + 2) * g, NC)];
+    const bool second = o >= m0;
+    const u64 x = s[o];
+    int lo = second ? a0 : m0, hi = second ? m0 : b1;  // the sibling run: how many of its keys are below x
+    const int sib0 = lo;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (s[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    const int pos = a0 + (o - (second ? m0 : a0)) + (lo - sib0);
+    if (!LAST) {
+        dst[ob + pos] = x;
+    } else if (pos < nk) {
+        const long long idx = (long long)(x & 0xFFFFFFFFull);
+        ep.keep_idx[(long long)b * ep.out_cap + pos] = idx;
+        const float *det = ep.det + ((long long)b * ep.cap + idx) * ep.D;
+        float *out = ep.out_det + ((long long)b * ep.out_cap + pos) * ep.D;
+        if ((ep.D & 1) == 0 && ((((uintptr_t)det) | ((uintptr_t)out)) & 7) == 0) {
+            for (int q = 0; q < (ep.D >> 1); ++q) reinterpret_cast<float2 *>(out)[q] = reinterpret_cast<const float2 *>(det)[q];
+        } else {
+            for (int q = 0; q < ep.D; ++q) out[q] = det[q];
+        }
     }
 }
 
@@ -1775,6 +1909,7 @@ static int vx_set_max_lds(vx_attr_cache &c, const void *kernel, int bytes) {
 struct vx_nms_ws {
     u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel;
     int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
+    int *part_runs;                                           // [B][VX_PART_MAX_CLASSES + 1] boundaries of the kept runs
     size_t bytes;
 };
 
@@ -1795,6 +1930,7 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.part_cursor = (int *)(p + off); off += vx_align256n((size_t)B * VX_PART_MAX_CLASSES * sizeof(int));
     w.part_segstart = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
     w.sel2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+    w.part_runs = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
     w.bytes = off;
     return w;
 }
@@ -1888,6 +2024,11 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     d_counts = w.sel;                                  // from here on: only the images the kernel above left
 
     const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
+    const bool topk_select = top_k > 0 && top_k <= VX_TOPK_MAX;
+    // kept keys as ordered per-class runs + merge rounds instead of the second sort (not with the top_k select,
+    // which reads an unordered key set)
+    const bool run_merge = partitioned && !topk_select;
+    vx_part_args pa = {};
     if (partitioned) {
         static vx_attr_cache part_attr_set;
         if (vx_set_max_lds(part_attr_set, (const void *)vx_k_part_sweep<VX_SORT_CHMAX, 1024>, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK)
@@ -1897,6 +2038,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.hist = w.part_hist; a.cursor = w.part_cursor; a.segstart = w.part_segstart; a.sel2 = w.sel2;
         a.keys1 = w.keys1; a.keys2 = w.keys2; a.sbox = w.sbox; a.sarea = w.sarea; a.count2 = w.count2; a.status = d_status;
         a.iou_count = vx_iou_counter();
+        a.ordered = run_merge ? 1 : 0;
+        pa = a;
         if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
             return VX_ERR_LAUNCH;
         dim3 tiles((capacity + VX_PART_TILE - 1) / VX_PART_TILE, B);
@@ -1935,13 +2078,27 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     if (X < 1) X = 1;
     vx_prof_begin(VX_PROF_SWEEP, st);
     hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
-                       w.count2, vx_iou_counter());
+                       w.count2, vx_iou_counter(), run_merge ? w.part_hist : nullptr);
     vx_prof_end(VX_PROF_SWEEP, st);
     vx_prof_begin(VX_PROF_SORT2, st);
-    if (top_k > 0 && top_k <= VX_TOPK_MAX)             // only the first top_k keys are needed: select, then sort those
+    if (topk_select) {                                 // only the first top_k keys are needed: select, then sort those
         hipLaunchKernelGGL(vx_k_topk_select, dim3(B), dim3(1024), 0, st, w.keys2, w.count2, w.sel, p, ep);
-    else
+    } else if (!run_merge) {
         rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
+    } else {
+        {                                              // kept runs of every image left by vx_k_nms_image: keys2 -> keys1 -> keys2 ...
+            dim3 tiles((capacity + VX_RUNS_TILE - 1) / VX_RUNS_TILE, B), mtiles((capacity + VX_MERGE_TILE - 1) / VX_MERGE_TILE, B);
+            hipLaunchKernelGGL(vx_k_runs_compact, tiles, dim3(256), 0, st, pa, w.keys1, w.part_runs);
+            u64 *src = w.keys1, *dst = w.keys2;
+            for (int g = 1; g < n_classes; g <<= 1) {
+                if (2 * g < n_classes)
+                    hipLaunchKernelGGL(vx_k_runs_merge<false>, mtiles, dim3(VX_MERGE_TILE), 0, st, pa, src, dst, w.part_runs, g, ep);
+                else
+                    hipLaunchKernelGGL(vx_k_runs_merge<true>, mtiles, dim3(VX_MERGE_TILE), 0, st, pa, src, dst, w.part_runs, g, ep);
+                u64 *t = src; src = dst; dst = t;
+            }
+        }
+    }
     vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
