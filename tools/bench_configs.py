@@ -29,14 +29,27 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _timed(fn, steps, warmup):
+def _timed(fn, steps, warmup, fn_async=None):
+    """fn() = one synchronous step.  With fn_async (returns an object whose .result() materialises the step's
+    detections) the timed loop keeps two batches in flight exactly as bench.py's headline loop does (--depth 2)."""
     from vortex_amd import _lib as L
-    for _ in range(warmup):
-        out = fn()
+
+    def loop(n):
+        if fn_async is None:
+            for _ in range(n):
+                out = fn()
+            return out
+        prev = None
+        for _ in range(n):
+            cur = fn_async()
+            if prev is not None:
+                prev.result()
+            prev = cur
+        return prev.result()
+    loop(max(warmup, 1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = fn()
+    out = loop(steps)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     L.profile_enable(steps * 40)                      # separate pass: every kernel family bracketed by HIP events
@@ -71,11 +84,30 @@ def _nms_record(tests, nms_ms):
                     "2.4 GHz / 13 lane-ops per test"}
 
 
-def _roof(kernel, ms, algo_bytes):
+def _traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` in configuration `tag` from the newest committed profiles/traffic_r*.json
+    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `tools/bench_configs.py <tag>`, tools/prof_r02.sh)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            k = json.load(open(f)).get(tag, {}).get("kernels", {}).get(kernel)
+        except Exception:
+            k = None
+        if k:
+            return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"], os.path.relpath(f, root)
+    return None, None
+
+
+def _roof(kernel, ms, algo_bytes, tag=None, pmc_kernel=None):
     ach = algo_bytes / (ms * 1e-3) / 1e9
+    traffic, src = _traffic(tag, pmc_kernel or kernel) if tag else (None, None)
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": int(algo_bytes),
-            "traffic": None, "traffic_source": "not collected in this run (PMC passes are separate rocprofv3 runs: profiles/)"}
+            "traffic": traffic,
+            "traffic_source": ("%s: separate rocprofv3 --pmc passes of this configuration (FETCH_SIZE doubled as the guide "
+                               "prescribes); not measured in this run" % src) if traffic else
+                              "not collected (PMC passes are separate rocprofv3 runs: profiles/)"}
 
 
 NMS_KERNELS = ("vx_k_nms_image", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather", "vx_k_nms_sweep", "vx_k_sort(keys2)+output")
@@ -111,7 +143,7 @@ def make_priors(img_size=640):
     return torch.cat(out, 0).float().contiguous()
 
 
-def prior_cfg(B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
+def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     import vortex_amd as V
     from vortex_amd import ops
     dev = _dev()
@@ -136,7 +168,7 @@ def prior_cfg(B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
-           "roofline": _roof("vx_k_prior_decode", kern["vx_k_prior_decode"], algo)}
+           "roofline": _roof("vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
     tests = _iou_tests(fn)
     rec["nms"] = _nms_record(tests, sum(kern.get(k, 0.0) for k in NMS_KERNELS))
     if cpu_budget:
@@ -207,16 +239,22 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
     def fn():
         pre()
         return post(heads, st, it)
-    out, dt, kern = _timed(fn, steps, warmup)
+
+    def fn_async():
+        pre()
+        return post.forward_async(heads, st, it)
+    out, dt, kern = _timed(fn, steps, warmup, fn_async)
     cand = int(ops.yolo_fused_decode(heads, S, sthr).counts.sum())
-    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
+    tag = "yolo416_b256_" + kind
+    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "batches_in_flight": 2,
+           "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.2}}
     if kind == "resize720p":
         rec["roofline"] = _roof("vx_k_resize_fast (reported as vx_k_normalize/resize)", kern["vx_k_normalize/resize"],
-                                B * (3 * 720 * 1280 + 12 * S * S))
+                                B * (3 * 720 * 1280 + 12 * S * S), tag, "vx_k_resize_fast")
     else:
-        rec["roofline"] = _roof("vx_k_yolo_fused", kern["vx_k_yolo_fused"], B * bench.ALGO_BYTES_DECODE + 32 * cand)
+        rec["roofline"] = _roof("vx_k_yolo_fused", kern["vx_k_yolo_fused"], B * bench.ALGO_BYTES_DECODE + 32 * cand, tag)
     rec["nms"] = _nms_record(_iou_tests(fn), sum(kern.get(k, 0.0) for k in NMS_KERNELS))
     if cpu_budget:
         from oracle import vortex_oracle as O
@@ -239,8 +277,8 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
 
 
 CONFIGS = {
-    "fpn_ssd_640_b64": lambda **kw: prior_cfg(64, 0, 21, 0.3, **kw),
-    "retinaface_640_b128": lambda **kw: prior_cfg(128, 5, 2, 0.5, **kw),
+    "fpn_ssd_640_b64": lambda **kw: prior_cfg("fpn_ssd_640_b64", 64, 0, 21, 0.3, **kw),
+    "retinaface_640_b128": lambda **kw: prior_cfg("retinaface_640_b128", 128, 5, 2, 0.5, **kw),
     "nms_stress_100k_b32_top300": lambda **kw: stress_cfg(**kw),
     "yolo416_b256_dense": lambda **kw: yolo_cfg("dense", **kw),
     "yolo416_b256_resize720p": lambda **kw: yolo_cfg("resize720p", **kw),

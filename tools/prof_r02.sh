@@ -14,6 +14,7 @@ OUT=gpurun_out/prof_$TAG
 PASSES=${PASSES:-stats fetch write}
 rm -rf $OUT
 mkdir -p $OUT
+echo "python3 $*" > $OUT/command.txt
 for pass in $PASSES; do
     case $pass in
     stats) timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 "$@" > $OUT/bench_stats.json 2> $OUT/stats.err ;;

@@ -42,7 +42,7 @@ def pmc(path, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-def main(src, tag, rnd, workload):
+def main(src, tag, rnd, workload, dominant=None):
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     ks = one(os.path.join(src, "stats", "**", "*_kernel_stats.csv"))
@@ -66,10 +66,11 @@ def main(src, tag, rnd, workload):
         fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
         kernels[k] = {"FETCH_SIZE_KiB_avg": fk, "WRITE_SIZE_KiB_avg": wk,
                       "hbm_read_bytes_per_launch": int(2 * fk * 1024), "hbm_write_bytes_per_launch": int(wk * 1024)}
-    dom = "vx_k_yolo_decode_rows" if workload == "unfused" else "vx_k_yolo_fused"
+    dom = dominant or ("vx_k_yolo_decode_rows" if workload == "unfused" else "vx_k_yolo_fused")
     entry = {"kernels": kernels, "dominant_kernel": dom,
              "correction": "reads = 2 * FETCH_SIZE KiB * 1024 (gfx950 half-count of wide coalesced reads); "
-                           "writes = WRITE_SIZE KiB * 1024; separate --pmc passes (tools/prof_%s.sh)" % rnd}
+                           "writes = WRITE_SIZE KiB * 1024; separate --pmc passes (tools/prof_%s.sh)" % rnd,
+             "command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else None}
     if dom in kernels:
         entry["hbm_bytes_per_launch"] = kernels[dom]["hbm_read_bytes_per_launch"] + kernels[dom]["hbm_write_bytes_per_launch"]
     traffic[workload] = entry
@@ -82,4 +83,4 @@ if __name__ == "__main__":
     tag = sys.argv[2] if len(sys.argv) > 2 else "r01_default"
     rnd = sys.argv[3] if len(sys.argv) > 3 else "r01"
     workload = sys.argv[4] if len(sys.argv) > 4 else "default"
-    main(src, tag, rnd, workload)
+    main(src, tag, rnd, workload, sys.argv[5] if len(sys.argv) > 5 else None)
