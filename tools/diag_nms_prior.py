@@ -12,13 +12,20 @@ from vortex_amd import _lib as L, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "retinaface"
-B, Lm, NL, sthr = (128, 5, 2, 0.5) if which == "retinaface" else (64, 0, 21, 0.3)
-P = 50400
-priors = make_priors(640).to(dev)
-g = torch.Generator(device=dev).manual_seed(5)
-x = torch.randn(B, P, 4 + 2 * Lm + NL, generator=g, device=dev)
-x[..., 4 + 2 * Lm + 1:] = x[..., 4 + 2 * Lm + 1:] * 2 - 3
-c = ops.prior_decode(x, priors, Lm, sthr)
+if which == "dense":                                  # the headline pipeline's candidates at score_thr 0.06
+    import bench
+    B, NL, ithr = 256, 81, 0.2
+    _, heads = bench.synth_on_device(B, dev, seed=4321)
+    c = ops.yolo_fused_decode(heads, 416, 0.06)
+else:
+    B, Lm, NL, sthr = (128, 5, 2, 0.5) if which == "retinaface" else (64, 0, 21, 0.3)
+    ithr = 0.4
+    P = 50400
+    priors = make_priors(640).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, P, 4 + 2 * Lm + NL, generator=g, device=dev)
+    x[..., 4 + 2 * Lm + 1:] = x[..., 4 + 2 * Lm + 1:] * 2 - 3
+    c = ops.prior_decode(x, priors, Lm, sthr)
 lib = L.lib()
 K = c.R
 D = c.D
@@ -29,7 +36,7 @@ out_det = torch.empty((B, K, D), device=dev)
 L.profile_enable(64)
 for it in range(3):
     rc = lib.vx_batched_nms(c.boxes.data_ptr(), c.scores.data_ptr(), c.cls.data_ptr(), c.det.data_ptr(),
-                            c.counts.data_ptr(), B, K, D, NL - 1, 0.4, 0, keep_idx.data_ptr(), out_det.data_ptr(),
+                            c.counts.data_ptr(), B, K, D, NL - 1, ithr, 0, keep_idx.data_ptr(), out_det.data_ptr(),
                             c.keep_counts.data_ptr(), K, c.status.data_ptr(), ws.data_ptr(), nb, L.stream_ptr(dev))
     assert rc == 0
 torch.cuda.synchronize()

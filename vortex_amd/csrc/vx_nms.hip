@@ -52,9 +52,22 @@ __device__ __forceinline__ bool vx_box_in_range2(const vx_f4 &b) {
 __device__ __forceinline__ int vx_range_bits(const vx_f4 &b) {
     return (vx_box_in_range(b) ? 0 : VX_STATUS_RANGE) | (vx_box_in_range2(b) ? 0 : VX_STATUS_RANGE2);
 }
-__device__ __forceinline__ void vx_flag_range(int bits, int *status) {       // wave-level OR, one atomic per wave
+// Sets bits of the call's status word.  The word is one address for the whole launch: normalised boxes that stick out of
+// the image set VX_STATUS_RANGE2 in every wave, and thousands of atomics on one address serialise in L2 (measured:
+// +0.04 ms on the dense YOLO batch), so the atomic is only issued while the bits are not yet visible.
+__device__ __forceinline__ void vx_status_or(int *status, int bits) {
+    if (bits == 0) return;
+    if ((__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(status, bits);
+}
+__device__ __forceinline__ void vx_flag_range(int bits, int *status) {       // wave-level OR, at most one atomic per wave
     const bool a = __ballot(bits & VX_STATUS_RANGE) != 0ull, b2 = __ballot(bits & VX_STATUS_RANGE2) != 0ull;
-    if ((a || b2) && vx_lane() == 0) atomicOr(status, (a ? VX_STATUS_RANGE : 0) | (b2 ? VX_STATUS_RANGE2 : 0));
+    if ((a || b2) && vx_lane() == 0) vx_status_or(status, (a ? VX_STATUS_RANGE : 0) | (b2 ? VX_STATUS_RANGE2 : 0));
+}
+// ... into a word of the workgroup's LDS: the workgroup then issues ONE global atomic as its last instruction (a wave's
+// later loads queue behind its own atomic, and all workgroups of a launch reach their gather phase together)
+__device__ __forceinline__ void vx_flag_range_lds(int bits, int *s_bits) {
+    const bool a = __ballot(bits & VX_STATUS_RANGE) != 0ull, b2 = __ballot(bits & VX_STATUS_RANGE2) != 0ull;
+    if ((a || b2) && vx_lane() == 0) atomicOr(s_bits, (a ? VX_STATUS_RANGE : 0) | (b2 ? VX_STATUS_RANGE2 : 0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
     if (!final_stage || sp.epilogue == 0) return;
     if (sp.epilogue == 1) {
         // sorted position -> class-offset box  fl32(x + fl32(2049*cls))  (nms.py:94-96) and its area
+        int rbits = 0;
         for (int i = threadIdx.x; i < m; i += nt) {
             int gi = base + i;
             if (gi < n) {
@@ -286,13 +300,14 @@ __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, 
                 int idx = vx_key1_idx(key);
                 float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
                 vx_f4 bx = *reinterpret_cast<const vx_f4 *>(ep.boxes + ((long long)b * ep.cap + idx) * 4);
-                if (ep.guard) { const int rb = vx_range_bits(bx); if (rb) atomicOr(ep.status, rb); }
+                if (ep.guard) rbits |= vx_range_bits(bx);
                 bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
                 long long o = (long long)b * sp.stride + gi;
                 ep.sbox[o] = bx;
                 ep.sarea[o] = (bx.z - bx.x) * (bx.w - bx.y);
             }
         }
+        vx_flag_range(rbits, ep.status);
     } else {
         int nk = n;
         if (ep.top_k > 0) nk = min(nk, ep.top_k);
@@ -515,7 +530,7 @@ __device__ __forceinline__ void vx_build_pair_lut(unsigned short *lut) {
 __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, const float *__restrict__ sarea,
                                                const u64 *keys1, int lo, int n, const vx_thr &thr, u64 *wmask,
                                                const unsigned short *pair_lut, u64 *__restrict__ keys2,
-                                               int *count2, unsigned long long *iou_count = nullptr) {
+                                               int *count2, unsigned long long *iou_count = nullptr, int *kcount = nullptr) {
     const int lane = vx_lane();
     vx_f4 bx = {0.f, 0.f, 0.f, 0.f};
     float ar = 0.f;
@@ -542,18 +557,24 @@ __device__ __forceinline__ void vx_sweep_pairs(const vx_f4 *__restrict__ sbox, c
         __builtin_amdgcn_wave_barrier();
         const u64 row = wmask[lane];
         const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
-        u64 todo = alive;
+        const u64 has = __ballot(row != 0ull);       // only boxes that suppress somebody need a turn
+        u64 todo = alive & has;
         while (todo) {
             int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
             u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
                      (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
             alive &= ~mi;
-            todo = alive & ~((2ull << i) - 1ull);
+            todo = alive & has & ~((2ull << i) - 1ull);
         }
     }
     const bool mine = (alive >> lane) & 1ull;
     u64 key = mine ? keys1[lo + lane] : 0ull;
-    vx_emit_kept(alive, mine, key, keys2, count2);
+    if (kcount) {                                    // ordered run at keys2[0..*kcount)
+        vx_emit_kept_at(alive, mine, key, keys2, 0);
+        if (lane == 0) *kcount = __popcll(alive);
+    } else {
+        vx_emit_kept(alive, mine, key, keys2, count2);
+    }
 }
 
 // Wave routine: a segment of n <= 64*WT boxes, everything in registers.
@@ -1390,6 +1411,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
     __shared__ vx_spatial_smem SP;
+    __shared__ int s_rbits;
     const int b = blockIdx.y, c = blockIdx.x;
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
     const int lo = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
@@ -1401,6 +1423,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     const int nt = blockDim.x;
     const int npad = vx_next_pow2(len);
     u64 *kseg = a.keys1 + ob + lo;
+    if (threadIdx.x == 0) s_rbits = 0;
     for (int i = threadIdx.x; i < npad; i += nt) sk[i] = i < len ? kseg[i] : VX_KEY_SENTINEL;
     __syncthreads();
     vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
@@ -1420,7 +1443,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
         if (big) kseg[i] = key;
     }
-    vx_flag_range(oob, a.status);
+    vx_flag_range_lds(oob, &s_rbits);
     __syncthreads();
     const vx_thr T = vx_make_thr(p.thr);
     u64 *k2 = a.keys2 + ob + (a.ordered ? lo : 0);
@@ -1434,6 +1457,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
         vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
         vx_async_emit(A, kseg, k2, c2, kc);
     }
+    if (threadIdx.x == 0) vx_status_or(a.status, s_rbits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1650,6 +1674,7 @@ struct vx_image_args {
     float *out_det;
     int *keep_counts, *status;
     int *seg;         // [B][VX_MAX_CLASSES] class-segment starts in sorted order
+    int *segk;        // [B][VX_MAX_CLASSES] kept boxes of each segment (ordered emission, see the run merge below)
     int *sel;         // optional [B]: out, n if the image has more than n_max candidates (left to the multi-kernel path) else 0
     int n_max;
     size_t lds_bytes; // dynamic LDS of the launch
@@ -1702,7 +1727,6 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
         bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
         ar = (bx.z - bx.x) * (bx.w - bx.y);
     }
-    if (p.n_classes != 1) vx_flag_range(oob, a.status);
     const vx_thr T = vx_make_thr(p.thr);
     u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     u64 todo = alive;
@@ -1732,14 +1756,16 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
         float *dst = a.out_det + ((long long)b * p.out_cap + lane) * p.D;
         for (int q = 0; q < p.D; ++q) dst[q] = src[q];
     }
+    if (p.n_classes != 1) vx_flag_range(oob, a.status);      // last: nothing of this wave queues behind the atomic
 }
 
+#define VX_IMG_MERGE_PER_THREAD 8        // positions of the run merge whose run index a thread keeps in registers
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
     __shared__ vx_spatial_smem SP;
-    __shared__ int s_big[VX_SWEEP_MAXBIG][2];
-    __shared__ int s_nbig, s_count2, s_nseg;
+    __shared__ int s_big[VX_SWEEP_MAXBIG][3];
+    __shared__ int s_nbig, s_count2, s_nseg, s_rbits;
     __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
     __shared__ u64 s_wmask[16][64];
     __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
@@ -1777,7 +1803,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         sk[i] = key;
     }
     if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
-    if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; }
+    if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; s_rbits = 0; }
     vx_build_pair_lut(s_pair_lut);
     __syncthreads();
     VX_STAMP(1);
@@ -1798,7 +1824,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         sb[i] = bx;
         sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
     }
-    if (p.n_classes != 1) vx_flag_range(oob, a.status);
+    if (p.n_classes != 1) vx_flag_range_lds(oob, &s_rbits);
     __syncthreads();
     VX_STAMP(3);
     u64 *k2 = a.keys2 + ob;
@@ -1835,17 +1861,25 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     __syncthreads();
     const int nseg = s_nseg;
+    // Kept keys: every segment writes its kept keys IN ORDER to k2[lo ..] and their number to segk[s]; the runs are then
+    // merged in LDS (ceil(log2 nseg) rounds, one binary search per key) -- a fraction of the work of a second bitonic
+    // sort.  Needs two key buffers + the run boundaries in the launch's LDS; otherwise (or with one segment beyond
+    // the list) the kept keys go through the image's counter and are sorted.
+    const bool merge = nseg <= VX_MAX_CLASSES && n <= VX_IMG_MERGE_PER_THREAD * nt &&
+                       ((size_t)2 * n * sizeof(u64) + (size_t)(nseg + 1) * sizeof(int)) <= a.lds_bytes;
+    int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
     for (int s = wave; s < nseg; s += nw) {
         int lo = seg[s];
         int hi = s + 1 < nseg ? seg[s + 1] : n;
         int len = hi - lo;
         if (len <= 64) {
-            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, k2, &s_count2, a.iou_count);
+            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, merge ? k2 + lo : k2, &s_count2, a.iou_count,
+                           merge ? segk + s : nullptr);
         } else if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, sk, lo, len, T, k2, &s_count2, a.iou_count);
+            vx_sweep_wave(sb, sa, sk, lo, len, T, merge ? k2 + lo : k2, &s_count2, a.iou_count, merge ? segk + s : nullptr);
         } else if (lane == 0) {
             int q = atomicAdd(&s_nbig, 1);
-            if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; }
+            if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; s_big[q][2] = s; }
         }
     }
     __syncthreads();
@@ -1855,22 +1889,86 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
     for (int q = 0; q < nbig; ++q) {
         const int lo = s_big[q][0], len = s_big[q][1];
+        int *kc = merge ? segk + s_big[q][2] : nullptr;
+        u64 *kd = merge ? k2 + lo : k2;
         if (vx_sweep_spatial(SP, sk, a.lds_bytes, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr)) {
-            vx_spatial_emit(SP, kg + lo, k2, &s_count2);
+            vx_spatial_emit(SP, kg + lo, kd, &s_count2, kc);
         } else {
             vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
-            vx_async_emit(A, kg + lo, k2, &s_count2);
+            vx_async_emit(A, kg + lo, kd, &s_count2, kc);
         }
     }
     __syncthreads();
     VX_STAMP(5);
-    // kept keys back into global score order, then the outputs
-    const int n2 = s_count2;
-    const int npad2 = vx_next_pow2(max(n2, 1));
-    __syncthreads();                       // everyone has read s_count2 / finished with keys1 in sk
-    for (int i = threadIdx.x; i < npad2; i += nt) sk[i] = i < n2 ? k2[i] : VX_KEY_SENTINEL;
-    __syncthreads();
-    vx_bitonic_sort_lds(sk, npad2, 0, 2, npad2);
+    int n2;
+    if (merge) {
+        // run boundaries R[0..nseg] = exclusive scan of the kept counts (4 per thread, wave scan, wave totals)
+        u64 *bufA = sk, *bufB = sk + n;
+        int *R = reinterpret_cast<int *>(sk + 2 * (size_t)n);
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int s = threadIdx.x * 4 + q; v[q] = s < nseg ? segk[s] : 0; tot += v[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_gcnt[wave] = incl;
+        __syncthreads();
+        int run = incl - tot;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_gcnt[w2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int s = threadIdx.x * 4 + q; if (s < nseg) R[s] = run; run += v[q]; }
+        if (threadIdx.x == nt - 1) { R[nseg] = run; s_count2 = run; }     // nt * 4 >= VX_MAX_CLASSES >= nseg
+        __syncthreads();
+        n2 = s_count2;
+        // runs -> bufA, adjacent; rr = the run of each of this thread's positions (positions keep their run: merged
+        // groups are unions of neighbouring runs)
+        int rr[VX_IMG_MERGE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < VX_IMG_MERGE_PER_THREAD; ++k) {
+            const int o = threadIdx.x + k * nt;
+            rr[k] = 0;
+            if (o < n2) {
+                int lo2 = 0, hi2 = nseg;             // invariant R[lo2] <= o < R[hi2]
+                while (hi2 - lo2 > 1) { int mid = (lo2 + hi2) >> 1; if (R[mid] <= o) lo2 = mid; else hi2 = mid; }
+                rr[k] = lo2;
+                bufA[o] = k2[seg[lo2] + (o - R[lo2])];
+            }
+        }
+        __syncthreads();
+        u64 *src = bufA, *dst = bufB;
+        // (A/B: advancing four searches of a thread in lockstep to overlap their LDS latencies was slower, 57 k vs
+        // 48 k cycles on the dense YOLO batch -- with 16 waves per CU the phase is bound by its instruction count)
+        for (int lg = 0; (1 << lg) < nseg; ++lg) {
+#pragma unroll
+            for (int k = 0; k < VX_IMG_MERGE_PER_THREAD; ++k) {
+                const int o = threadIdx.x + k * nt;
+                if (o < n2) {
+                    const int G = (rr[k] >> lg) & ~1;    // groups of 2^lg runs; groups G and G + 1 are merged
+                    const int a0 = R[min(G << lg, nseg)], m0 = R[min((G + 1) << lg, nseg)], b1 = R[min((G + 2) << lg, nseg)];
+                    const bool second = o >= m0;
+                    const u64 x = src[o];
+                    int lo2 = second ? a0 : m0, hi2 = second ? m0 : b1;
+                    const int sib0 = lo2;
+                    while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (src[mid] < x) lo2 = mid + 1; else hi2 = mid; }
+                    dst[a0 + (o - (second ? m0 : a0)) + (lo2 - sib0)] = x;
+                }
+            }
+            __syncthreads();
+            u64 *t = src; src = dst; dst = t;
+        }
+        if (src != sk) {                             // the outputs below read sk
+            for (int i = threadIdx.x; i < n2; i += nt) dst[i] = src[i];
+            __syncthreads();
+        }
+    } else {
+        // kept keys back into global score order by a second sort
+        n2 = s_count2;
+        const int npad2 = vx_next_pow2(max(n2, 1));
+        __syncthreads();                       // everyone has read s_count2 / finished with keys1 in sk
+        for (int i = threadIdx.x; i < npad2; i += nt) sk[i] = i < n2 ? k2[i] : VX_KEY_SENTINEL;
+        __syncthreads();
+        vx_bitonic_sort_lds(sk, npad2, 0, 2, npad2);
+    }
     VX_STAMP(6);
     int nk = n2;
     if (p.top_k > 0) nk = min(nk, p.top_k);
@@ -1887,6 +1985,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     __syncthreads();
     VX_STAMP(7);
+    if (threadIdx.x == 0) vx_status_or(a.status, s_rbits);
 #undef VX_STAMP
 }
 
@@ -1907,7 +2006,7 @@ static int vx_set_max_lds(vx_attr_cache &c, const void *kernel, int bytes) {
 }
 
 struct vx_nms_ws {
-    u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *sel;
+    u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *segk; int *sel;
     int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
     int *part_runs;                                           // [B][VX_PART_MAX_CLASSES + 1] boundaries of the kept runs
     size_t bytes;
@@ -1925,6 +2024,7 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.count2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.stamps = (u64 *)(p + off); off += vx_align256n((size_t)B * VX_STAMP_WORDS * sizeof(u64));   // per-image phase clocks (diagnostics)
     w.seg = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
+    w.segk = (int *)(p + off); off += vx_align256n((size_t)B * VX_MAX_CLASSES * sizeof(int));
     w.sel = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.part_hist = (int *)(p + off); off += (size_t)B * VX_PART_MAX_CLASSES * sizeof(int);
     w.part_cursor = (int *)(p + off); off += vx_align256n((size_t)B * VX_PART_MAX_CLASSES * sizeof(int));
@@ -2001,7 +2101,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.p = p; a.boxes = d_boxes; a.scores = d_scores; a.det = d_det; a.cls = (const long long *)d_cls;
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
-        a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg;   // phase clocks only while profiling
+        a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg; a.segk = w.segk;   // phase clocks only while profiling
         a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only;
         a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
