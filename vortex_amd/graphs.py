@@ -73,6 +73,8 @@ class GraphedPostProcess:
         self._n += 1
         if c.pending is not None:
             c.pending.detach()                              # its rows leave the static buffer before the replay rewrites it
+            if c.pending._copied is not None:               # (stream order: the replay runs after that copy)
+                torch.cuda.current_stream(self.device).wait_event(c.pending._copied)
         c.graph.replay()
         self.preprocessed = c.preprocessed
         c.pending = _GraphPending(c.packed, c.meta, c.host)
@@ -88,6 +90,7 @@ class _GraphPending(PendingDetections):
     detections somebody still holds or has yet to collect."""
     _rows = None
     _counts = None
+    _copied = None
 
     def detach(self):
         if self._counts is None:
@@ -96,7 +99,9 @@ class _GraphPending(PendingDetections):
             B = (len(m) - 1) // 2
             self._status, self._counts = int(m[-1]), m[B:2 * B]
             self._rows = self.packed[:sum(self._counts)].clone()
-            torch.cuda.current_stream(self._rows.device).synchronize()      # the copy is done before anything replays
+            # no host wait: the copy is ordered on its stream, and a replay into the same buffers waits for this event
+            self._copied = torch.cuda.Event()
+            self._copied.record(torch.cuda.current_stream(self._rows.device))
 
     def result(self):
         self.detach()
