@@ -21,6 +21,10 @@ struct vx_prior_params {
 //   LAYOUT 0 (any NCOL): rows padded to the odd stride NCP = NCOL | 1, four ds_write_b32 per load with the (row, col)
 //            of each element advanced incrementally (no per-element division); when NCOL % 4 == 0 (RetinaFace 16) a
 //            load never straddles a row and the carry disappears
+// A/B (round 2, MI355X): two tiles in flight (second register buffer, 8 tiles per workgroup) 0.095 -> 0.115 ms on the
+// RetinaFace batch, 0.078 -> 0.109 ms on FPN-SSD: the conditional prefetch at the end of a group makes the compiler
+// wait with vmcnt(0) wherever an older load is consumed (vmcnt retires in order), and the registers cost a wave of
+// occupancy.  Parking the tile's priors in LDS before the prefetch (so that no load is consumed behind it): no change.
 #define VX_PRIOR_TPW 4
 // MAXQ = 16-B loads per thread and tile = ceil(NCOL / 4): 4 (NCOL <= 16), 8 (<= 32) or 16 (<= 63)
 
