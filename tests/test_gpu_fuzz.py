@@ -53,6 +53,42 @@ def test_fuzz_batched_nms(seed):
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), (seed, thr, boxes.shape)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_declared_classes_beyond_the_single_launch_kernel(seed):
+    """Capacities beyond 16384 with the class count declared: class-partitioned sort + sweep (chain, spatial or wave
+    routine per segment; inverted / zero-area boxes are not "tame" and must fall back to the chain sweep), kept keys as
+    ordered runs + merge rounds (no top_k, or a top_k beyond the radix select) or the select (small top_k), two images
+    of different fill per call."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    K = int(torch.randint(17000, 45000, (1,), generator=g))
+    C = [4, 20, 80, 256][seed % 4]
+    kind = ["normal", "grid", "dup", "inverted"][(seed // 2) % 4]
+    top_k = [None, 3000, 100][seed % 3]
+    thr = [0.3, 0.45, 0.6][seed % 3]
+    B = 2
+    counts = torch.tensor([K, int(K * 0.6)], dtype=torch.int32)
+    boxes = torch.stack([_boxes(kind, K, g) for _ in range(B)]).contiguous()
+    scores = torch.rand(B, K, generator=g)
+    if seed % 4 == 1:
+        scores = (scores * 64).floor() / 64
+    cls = torch.randint(0, C, (B, K), generator=g)
+    if seed % 5 == 0:                                    # one dominant class: a segment beyond the partitioned path
+        cls[0, : int(K * 0.8)] = C - 1
+    det = torch.cat((boxes, scores[..., None], cls[..., None].float()), 2)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV),
+                                                             counts.to(DEV), thr, n_classes=C, top_k=top_k)
+    assert ops.status_ok(int(status.item()))
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([thr]))
+        if top_k:
+            ref = ref[:top_k]
+        kc = int(keep_counts[b].item())
+        assert kc == ref.numel(), (seed, b, kc, ref.numel())
+        assert torch.equal(keep_idx[b, :kc].cpu(), ref), (seed, b)
+        assert torch.equal(out_det[b, :kc].cpu(), det[b, ref]), (seed, b)
+
+
 @pytest.mark.parametrize("K", [17000, 33000])
 def test_highest_class_index_on_the_multi_kernel_path(K):
     """Class 4095 (the last one a key can hold) with more candidates than the single-launch kernel sorts: its
