@@ -933,6 +933,11 @@ __device__ __forceinline__ void vx_sweep_async(vx_async_smem_t<MAXTILES> &S, voi
 // one workgroup barrier per phase.  Alive state is kept by rank, so the chain reads the word of its next tile directly.
 // Needs every box tame, a threshold inside the bracket's range and 20 bytes of scratch LDS per box (the caller falls
 // back to the chain sweep otherwise).
+// A/B on MI355X (RetinaFace b128 nms_image / FPN-SSD b64 sweep / stress b32 sweep, ms; baseline 0.648 / 0.61 / 0.605):
+//   in-tile resolve by a sequential scan on the chain wave instead of prebuilt rows (8-wave workgroups): - / 0.655 / 0.614
+//   s_setprio 3 on the chain wave: 0.647 / 0.622 / 0.608 (no effect: the workgroup is bound by its instruction count,
+//     the appliers' trips are 60 % of it, not by the chain's latency)
+//   kept boxes of a trip by v_readlane out of the wave's registers instead of LDS reads: 0.800 / 0.749 / 0.725
 #define VX_SP_CELLS 256
 
 struct vx_spatial_smem {
