@@ -256,6 +256,31 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
     else:
         rec["roofline"] = _roof("vx_k_yolo_fused", kern["vx_k_yolo_fused"], B * bench.ALGO_BYTES_DECODE + 32 * cand, tag)
     rec["nms"] = _nms_record(_iou_tests(fn), sum(kern.get(k, 0.0) for k in NMS_KERNELS))
+    if kind == "resize720p":
+        # the letterbox mode of the same kernel (aspect kept: 416 x 234 of the 416 x 416 output is resized, the rest is
+        # the pad value) and the plain u8 -> u8 resize of runtime.resize_batch, kernel time only
+        def _kernel_ms(f):
+            for _ in range(3):
+                f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 20
+        sh = min(S / 720.0, S / 1280.0)
+        Hl, Wl = int(round(720 * sh)), int(round(1280 * sh))
+        lb_ms = _kernel_ms(lambda: ops.preprocess(frames, mean, std, 255, out_size=(S, S), letterbox=True))
+        lb_bytes = B * (3 * 720 * 1280 + 12 * S * S)
+        u8_out = torch.empty((B, S, S, 3), dtype=torch.uint8, device=dev)
+        u8_ms = _kernel_ms(lambda: ops.resize_u8(frames, (S, S), out=u8_out))
+        u8_bytes = B * (3 * 720 * 1280 + 3 * S * S)
+        rec["variants"] = {
+            "letterbox": {"kernel_ms": round(lb_ms, 5), "resized_area": [Hl, Wl], "algorithmic_bytes_per_launch": lb_bytes,
+                          "frac_of_8TBps": round(lb_bytes / (lb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "resize_u8_only": {"kernel_ms": round(u8_ms, 5), "algorithmic_bytes_per_launch": u8_bytes,
+                               "frac_of_8TBps": round(u8_bytes / (u8_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     if cpu_budget:
         from oracle import vortex_oracle as O
         n = 2
