@@ -224,6 +224,30 @@ def test_optimistic_nms_small_and_deferred_608():
             assert torch.equal(res[b].cpu(), c.det[b, :k].cpu()[keep])
 
 
+def test_prior_postprocess_async_with_and_without_the_optimistic_launch():
+    """PriorBoxPostProcess.forward_async at P = 50400 with images beyond 16384 candidates: by default the single-launch
+    bet is lost (VX_STATUS_DEFERRED) and result() redoes the batch; with `optimistic_nms = False` the general path is
+    enqueued directly and nothing is deferred.  Same tuples either way."""
+    P, L, NL, B = 50400, 0, 21, 2
+    priors = O.make_priors(640)
+    x = O.synth_prior_head(B, P, L, NL, seed=91)
+    x[..., 5:] = x[..., 5:] * 2 - 1                       # most rows pass: ~30k candidates per image
+    st, it = torch.tensor([0.3]), torch.tensor([0.4])
+    pp = V.PriorBoxPostProcess(priors, n_landmarks=L).to(DEV)
+    xd = x.to(DEV)
+    ref = pp(xd, st, it)
+    assert max(int(r.shape[0]) for r in ref) > 0
+    pend = pp.forward_async(xd, st, it)
+    res = pend.result()
+    assert bool(pend._host[-1].item() & V._lib.VX_STATUS_DEFERRED)
+    pp.optimistic_nms = False
+    pend2 = pp.forward_async(xd, st, it)
+    res2 = pend2.result()
+    assert not bool(pend2._host[-1].item() & V._lib.VX_STATUS_DEFERRED)
+    for a, b, c in zip(ref, res, res2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_tail_stream_pipeline_equals_single_stream():
     """vx_yolo_fused_postprocess_overlapped (NMS + packing on a second stream behind the decode) returns the same
     tuples as the single-stream call, batch after batch with results collected one batch late."""

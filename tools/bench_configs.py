@@ -162,10 +162,18 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     def fn():
         norm(img)
         return pp(x, st, it)
-    out, dt, kern = _timed(fn, steps, warmup)
+
+    def fn_async():
+        norm(img)
+        return pp.forward_async(x, st, it)
     cand = int(ops.prior_decode(x, priors, Lm, sthr).counts.sum())
+    # two batches in flight like the headline loop; a batch whose images exceed the single-launch NMS kernel goes
+    # straight to the general path (the optimistic launch would only be repeated)
+    pp.optimistic_nms = cand // B <= ops.NMS_SINGLE_LAUNCH_MAX
+    out, dt, kern = _timed(fn, steps, warmup, fn_async)
     algo = B * P * NCOL * 4 + P * 16 + cand * (32 + 8 * Lm)         # rows + priors once + staged survivor records
-    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "kernels_ms": kern,
+    rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B, "batches_in_flight": 2,
+           "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
            "roofline": _roof("vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}

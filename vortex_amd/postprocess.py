@@ -192,8 +192,10 @@ class BatchedNMSPostProcess(BasicNMSPostProcess):
         c = self.decoder.decode_batch(input, score_threshold)
         ithr, hint = _f(iou_threshold), self.n_classes_hint(input)
         # capacity beyond the single-launch NMS kernel (prior-box models): bet on every image being small; the rare
-        # batch that is not comes back with VX_STATUS_DEFERRED and is redone by the general path in result()
-        optimistic = c.R > ops.NMS_SINGLE_LAUNCH_MAX
+        # batch that is not comes back with VX_STATUS_DEFERRED and is redone by the general path in result().
+        # A caller whose images routinely hold more than 16384 candidates sets `optimistic_nms = False` on the module:
+        # the general path is then enqueued at once and stays asynchronous
+        optimistic = c.R > ops.NMS_SINGLE_LAUNCH_MAX and getattr(self, "optimistic_nms", True)
         _, out_det, keep_counts, _ = ops.candidates_nms(c, ithr, hint, self.top_k, optimistic=optimistic)
         pend = PendingDetections.packing(out_det, keep_counts, c.meta)
         if optimistic:
