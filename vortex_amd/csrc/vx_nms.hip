@@ -1523,6 +1523,9 @@ __global__ __launch_bounds__(256) void vx_k_runs_compact(vx_part_args a, u64 *__
 
 // one key per thread: the binary search is a chain of dependent L2 reads, so the launch wants as many of them in
 // flight as it can get.  LAST: the final round writes the outputs (the second sort's epilogue) instead of the keys.
+// (A/B: a wave-cooperative search -- the places of a wave's first and last key by two 32-ary searches, the sibling keys
+// between them loaded once, every lane counting with shuffles: 3 dependent reads instead of 11 -- left the round at
+// 19.5 us on the FPN-SSD batch: the round is bound by the per-workgroup start-up chain, not by the search.)
 #define VX_MERGE_TILE 256
 template <bool LAST>
 __global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a, const u64 *__restrict__ src,
