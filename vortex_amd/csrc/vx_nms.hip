@@ -1533,24 +1533,29 @@ __global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a,
                                                                 vx_epi_params ep) {
     __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
     const int b = blockIdx.y;
-    if (!vx_runs_load(a, R, b, s_R)) return;
     const int NC = a.p.n_classes;
-    const int total = s_R[NC];
+    if (a.sel[b] == 0) return;                       // finished by vx_k_nms_image
+    // most workgroups of the grid (sized for the capacity) lie behind the image's kept keys: they leave after one
+    // scalar load, before the boundary table and its barrier
+    const int total = R[b * (VX_PART_MAX_CLASSES + 1) + NC];
     int nk = total;
     if (LAST) {
         if (ep.top_k > 0) nk = min(nk, ep.top_k);
         nk = min(nk, ep.out_cap);
         if (blockIdx.x == 0 && threadIdx.x == 0) ep.keep_counts[b] = nk;
     }
+    if ((int)(blockIdx.x * VX_MERGE_TILE) >= total) return;
     const int o = blockIdx.x * VX_MERGE_TILE + threadIdx.x;
-    if (o >= total) return;
     const long long ob = (long long)b * a.p.npad_cap;
     const u64 *s = src + ob;
+    const u64 x_early = o < total ? s[o] : 0ull;     // requested before the table load: the two latencies overlap
+    vx_runs_load(a, R, b, s_R);
+    if (o >= total) return;
     const int r = vx_runs_find(s_R, NC, o);
     const int G = (r / g) & ~1;                      // groups of g runs; groups G and G + 1 are merged
     const int a0 = s_R[min(G * g, NC)], m0 = s_R[min((G + 1) * g, NC)], b1 = s_R[min((G + 2) * g, NC)];
     const bool second = o >= m0;
-    const u64 x = s[o];
+    const u64 x = x_early;
     int lo = second ? a0 : m0, hi = second ? m0 : b1;  // the sibling run: how many of its keys are below x
     const int sib0 = lo;
     while (lo < hi) {
