@@ -201,10 +201,13 @@ int vx_detr_decode(const float *d_in, int B, int Q, int n_logits, float score_th
  * Tolerance class (softmax/exp): 1e-5 relative on the probability; labels exact. */
 int vx_softmax_max(const float *d_in, int B, int n_classes, float *d_out, void *stream);
 
-/* Optimistic variant of vx_batched_nms (same arguments, same results) for capacity > 16384: ONE launch; images
- * with more than 16384 candidates are NOT processed, their keep count is 0 and VX_STATUS_DEFERRED is set in
- * *d_status -- the caller checks the bit after synchronising and, if set, repeats the call with vx_batched_nms.
- * No reference counterpart: it spares the launch-bound general path when candidates are few. */
+/* Optimistic variant of vx_batched_nms (same arguments, same results) for capacity > 16384: only the cheap paths are
+ * launched.  Without a class count in 4..256: ONE launch; images with more than 16384 candidates are NOT processed.
+ * With 4 <= n_classes <= 256: that launch plus the class-partitioned path (histogram, scatter, per-class sort + sweep,
+ * run merge / top-k select); images with ONE CLASS of more than 16384 candidates are not processed.  An unprocessed
+ * image has keep count 0 and VX_STATUS_DEFERRED is set in *d_status -- the caller checks the bit after synchronising
+ * and, if set, repeats the call with vx_batched_nms.  No reference counterpart: it spares the ~8 launches of the
+ * general path (global sort, per-class sweep), which find nothing to do in the common case. */
 int vx_batched_nms_small(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
                          const float *d_det, const int32_t *d_counts,
                          int B, int capacity, int D, int n_classes, float iou_threshold, int top_k,

@@ -212,7 +212,9 @@ def test_optimistic_nms_small_and_deferred_608():
     dheads = [h.to(DEV) for h in heads]
     it = torch.tensor([0.45])
     post = V.YoloV3FusedPostProcess(S)
-    for sthr, expect_deferred in ((0.9, False), (0.001, True)):
+    # 80 declared classes: the optimistic call also takes the class-partitioned path, so the dense batch (22 743
+    # candidates per image, no class beyond 16384) is finished without a redo as well
+    for sthr, expect_deferred in ((0.9, False), (0.001, False)):
         st = torch.tensor([sthr])
         pend = post.forward_async(dheads, st, it)
         res = pend.result()
@@ -224,28 +226,59 @@ def test_optimistic_nms_small_and_deferred_608():
             assert torch.equal(res[b].cpu(), c.det[b, :k].cpu()[keep])
 
 
-def test_prior_postprocess_async_with_and_without_the_optimistic_launch():
-    """PriorBoxPostProcess.forward_async at P = 50400 with images beyond 16384 candidates: by default the single-launch
-    bet is lost (VX_STATUS_DEFERRED) and result() redoes the batch; with `optimistic_nms = False` the general path is
-    enqueued directly and nothing is deferred.  Same tuples either way."""
-    P, L, NL, B = 50400, 0, 21, 2
+@pytest.mark.parametrize("NL", [21, 2])
+def test_prior_postprocess_async_with_and_without_the_optimistic_launch(NL):
+    """PriorBoxPostProcess.forward_async at P = 50400 with images beyond 16384 candidates.  20 classes: the optimistic
+    call finishes them through the class-partitioned path.  One class (RetinaFace layout): the bet is lost
+    (VX_STATUS_DEFERRED) and result() redoes the batch; with `optimistic_nms = False` the general path is enqueued
+    directly and nothing is deferred.  Same tuples either way."""
+    P, L, B = 50400, 0, 2
     priors = O.make_priors(640)
     x = O.synth_prior_head(B, P, L, NL, seed=91)
     x[..., 5:] = x[..., 5:] * 2 - 1                       # most rows pass: ~30k candidates per image
+    if NL == 2:
+        x[..., 5] = x[..., 5].abs() + 0.5                 # face logit above the background logit for most rows
+        x[..., 4] = -x[..., 4].abs()
     st, it = torch.tensor([0.3]), torch.tensor([0.4])
     pp = V.PriorBoxPostProcess(priors, n_landmarks=L).to(DEV)
     xd = x.to(DEV)
+    assert int(ops.prior_decode(xd, priors.to(DEV), L, float(st)).counts.max()) > 16384
     ref = pp(xd, st, it)
     assert max(int(r.shape[0]) for r in ref) > 0
     pend = pp.forward_async(xd, st, it)
     res = pend.result()
-    assert bool(pend._host[-1].item() & V._lib.VX_STATUS_DEFERRED)
+    assert bool(pend._host[-1].item() & V._lib.VX_STATUS_DEFERRED) == (NL == 2)
     pp.optimistic_nms = False
     pend2 = pp.forward_async(xd, st, it)
     res2 = pend2.result()
     assert not bool(pend2._host[-1].item() & V._lib.VX_STATUS_DEFERRED)
     for a, b, c in zip(ref, res, res2):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_optimistic_call_defers_an_image_with_an_oversized_class():
+    """vx_batched_nms_small with 20 declared classes: image 0 (balanced classes, 30 000 boxes) is finished by the
+    class-partitioned path, image 1 has one class of ~19 000 boxes and is reported through VX_STATUS_DEFERRED with a keep
+    count of 0; vx_batched_nms then finishes both."""
+    K, C = 30000, 20
+    g = torch.Generator().manual_seed(5150)
+    boxes = torch.stack([_boxes("normal", K, g) for _ in range(2)]).contiguous()
+    scores = torch.rand(2, K, generator=g)
+    cls = torch.randint(0, C, (2, K), generator=g)
+    cls[1, : int(K * 0.64)] = 3
+    det = torch.cat((boxes, scores[..., None], cls[..., None].float()), 2)
+    args = (boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV), None, 0.45)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(*args, n_classes=C, optimistic=True)
+    assert int(status.item()) & V._lib.VX_STATUS_DEFERRED
+    ref0 = O.batched_nms(boxes[0], scores[0], cls[0], torch.tensor([0.45]))
+    kc = keep_counts.cpu().tolist()
+    assert kc[0] == ref0.numel() and kc[1] == 0
+    assert torch.equal(keep_idx[0, :kc[0]].cpu(), ref0)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(*args, n_classes=C)
+    assert ops.status_ok(int(status.item()))
+    for b in range(2):
+        ref = O.batched_nms(boxes[b], scores[b], cls[b], torch.tensor([0.45]))
+        assert int(keep_counts[b]) == ref.numel() and torch.equal(keep_idx[b, :ref.numel()].cpu(), ref)
 
 
 def test_tail_stream_pipeline_equals_single_stream():

@@ -1321,6 +1321,9 @@ struct vx_part_args {
     float *sarea;
     int *count2, *status;
     unsigned long long *iou_count;   // optional: useful lane-level IoU tests executed (measurement only)
+    int defer;             // != 0 (optimistic call): an image with a segment beyond VX_SORT_CHMAX is only reported
+                           //    (VX_STATUS_DEFERRED, keep count 0): the general path is not launched
+    int *keep_counts;
     int ordered;           // 1: the kept keys of class c go, in order, to keys2[segstart[c]..) and their number to
                            //    hist[b][c] (the run merge below takes them from there); 0: keys2 through count2
 };
@@ -1389,7 +1392,10 @@ __global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c <= NC; c += blockDim.x) a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c] = s_start[c];
-        if (threadIdx.x == 0) a.sel2[b] = s_over ? n : 0;
+        if (threadIdx.x == 0) {
+            a.sel2[b] = s_over ? n : 0;
+            if (s_over && a.defer) { atomicOr(a.status, VX_STATUS_DEFERRED); a.keep_counts[b] = 0; }
+        }
     }
     if (s_over) return;                              // the general path redoes this image from its inputs
     const long long ib = (long long)b * a.p.cap;
@@ -1473,7 +1479,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
 #define VX_RUNS_TILE 1024
 
 __device__ __forceinline__ bool vx_runs_load(const vx_part_args &a, const int *__restrict__ R, int b, int *s_R) {
-    if (a.sel[b] == 0) return false;                 // finished by vx_k_nms_image
+    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return false;      // finished by vx_k_nms_image / deferred
     for (int c = threadIdx.x; c <= a.p.n_classes; c += blockDim.x) s_R[c] = R[b * (VX_PART_MAX_CLASSES + 1) + c];
     __syncthreads();
     return true;
@@ -1492,7 +1498,7 @@ __device__ __forceinline__ int vx_runs_find(const int *s_R, int NC, int o) {
 __global__ __launch_bounds__(256) void vx_k_runs_compact(vx_part_args a, u64 *__restrict__ dst, int *__restrict__ R) {
     __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
     const int b = blockIdx.y;
-    if (a.sel[b] == 0) return;
+    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return;
     const int NC = a.p.n_classes;
     if (threadIdx.x < 64) {                          // exclusive scan of the kept counts (<= 256: 4 per lane)
         const int lane = threadIdx.x;
@@ -1534,7 +1540,7 @@ __global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a,
     __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
     const int b = blockIdx.y;
     const int NC = a.p.n_classes;
-    if (a.sel[b] == 0) return;                       // finished by vx_k_nms_image
+    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return;      // finished by vx_k_nms_image / deferred
     // most workgroups of the grid (sized for the capacity) lie behind the image's kept keys: they leave after one
     // scalar load, before the boundary table and its barrier
     const int total = R[b * (VX_PART_MAX_CLASSES + 1) + NC];
@@ -2106,6 +2112,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     // a handful per image whatever the capacity); the multi-kernel path below then only works on the others
     // (sel[b] = their count, 0 = done) -- for an all-small batch its launches find nothing to do.
     const bool all_fit = npad_cap <= VX_SORT_CHMAX;
+    const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
     {
         static vx_attr_cache image_attr_set;
         if (vx_set_max_lds(image_attr_set, (const void *)vx_k_nms_image, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK)
@@ -2115,7 +2122,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg; a.segk = w.segk;   // phase clocks only while profiling
-        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only;
+        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only && !partitioned;
         a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
         int threads = lds_keys >= 1024 ? 1024 : 256;
@@ -2132,11 +2139,10 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
         hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), lds, st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
-        if (all_fit || small_only) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+        if (all_fit || (small_only && !partitioned)) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
     d_counts = w.sel;                                  // from here on: only the images the kernel above left
 
-    const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
     const bool topk_select = top_k > 0 && top_k <= VX_TOPK_MAX;
     // kept keys as ordered per-class runs + merge rounds instead of the second sort (not with the top_k select,
     // which reads an unordered key set)
@@ -2152,6 +2158,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.keys1 = w.keys1; a.keys2 = w.keys2; a.sbox = w.sbox; a.sarea = w.sarea; a.count2 = w.count2; a.status = d_status;
         a.iou_count = vx_iou_counter();
         a.ordered = run_merge ? 1 : 0;
+        a.defer = small_only; a.keep_counts = d_keep_counts;
         pa = a;
         if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
             return VX_ERR_LAUNCH;
@@ -2168,31 +2175,37 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
     }
 
-    vx_prof_begin(VX_PROF_NMS_KEYS, st);
-    hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
-                       (const long long *)d_cls, d_counts, p, w.keys1, w.count2, d_status);
-    vx_prof_end(VX_PROF_NMS_KEYS, st);
+    // the general path (global sort, one workgroup per class for the sweep) takes the images left over; the optimistic
+    // call with declared classes has deferred them instead (vx_k_part_scatter) and skips these launches
+    const bool general = !(small_only && partitioned);
     vx_epi_params ep = {};
     ep.boxes = d_boxes; ep.sbox = w.sbox; ep.sarea = w.sarea; ep.cap = capacity;
     ep.status = d_status; ep.guard = n_classes != 1; ep.sel = w.sel;
     ep.det = d_det; ep.keep_idx = (long long *)d_keep_idx; ep.out_det = d_out_det; ep.keep_counts = d_keep_counts;
     ep.D = D; ep.top_k = top_k; ep.out_cap = out_capacity;
-    vx_prof_begin(VX_PROF_SORT1, st);
-    int rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
-    vx_prof_end(VX_PROF_SORT1, st);
-    if (rc != VX_OK) return rc;
-    // One class per wave and pass; <= 4096/256 = 16 <= VX_SWEEP_MAXBIG classes per workgroup.
-    // A/B on MI355X (tools/bench_configs.py), sweep kernel ms for (threads, workgroups per image):
-    //   FPN-SSD 20 classes x ~1500 boxes, b64:   (256,5) 2.43  (256,20) 0.88  (512,20) 0.84  (1024,20) 1.01
-    //   stress 80 classes x 1250 boxes, b32:     (256,20) 2.10 (256,80) 1.20  (512,80) 1.12  (1024,80) 1.51
-    // -> one workgroup per class (8 waves) up to 256 workgroups per image; <= 8 classes: 16 waves per class.
-    const int sweep_threads = n_classes <= 8 ? 1024 : 512;
-    int X = n_classes <= 256 ? n_classes : 256;
-    if (X < 1) X = 1;
-    vx_prof_begin(VX_PROF_SWEEP, st);
-    hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
-                       w.count2, vx_iou_counter(), run_merge ? w.part_hist : nullptr);
-    vx_prof_end(VX_PROF_SWEEP, st);
+    int rc = VX_OK;
+    if (general) {
+        vx_prof_begin(VX_PROF_NMS_KEYS, st);
+        hipLaunchKernelGGL(vx_k_nms_build_keys, dim3((capacity + 255) / 256, B), dim3(256), 0, st, d_scores,
+                           (const long long *)d_cls, d_counts, p, w.keys1, w.count2, d_status);
+        vx_prof_end(VX_PROF_NMS_KEYS, st);
+        vx_prof_begin(VX_PROF_SORT1, st);
+        rc = vx_sort_launch(w.keys1, d_counts, capacity, B, npad_cap, 1, ep, st);
+        vx_prof_end(VX_PROF_SORT1, st);
+        if (rc != VX_OK) return rc;
+        // One class per wave and pass; <= 4096/256 = 16 <= VX_SWEEP_MAXBIG classes per workgroup.
+        // A/B on MI355X (tools/bench_configs.py), sweep kernel ms for (threads, workgroups per image):
+        //   FPN-SSD 20 classes x ~1500 boxes, b64:   (256,5) 2.43  (256,20) 0.88  (512,20) 0.84  (1024,20) 1.01
+        //   stress 80 classes x 1250 boxes, b32:     (256,20) 2.10 (256,80) 1.20  (512,80) 1.12  (1024,80) 1.51
+        // -> one workgroup per class (8 waves) up to 256 workgroups per image; <= 8 classes: 16 waves per class.
+        const int sweep_threads = n_classes <= 8 ? 1024 : 512;
+        int X = n_classes <= 256 ? n_classes : 256;
+        if (X < 1) X = 1;
+        vx_prof_begin(VX_PROF_SWEEP, st);
+        hipLaunchKernelGGL(vx_k_nms_sweep, dim3(X, B), dim3(sweep_threads), 0, st, w.keys1, w.sbox, w.sarea, d_counts, p, w.keys2,
+                           w.count2, vx_iou_counter(), run_merge ? w.part_hist : nullptr);
+        vx_prof_end(VX_PROF_SWEEP, st);
+    }
     vx_prof_begin(VX_PROF_SORT2, st);
     if (topk_select) {                                 // only the first top_k keys are needed: select, then sort those
         hipLaunchKernelGGL(vx_k_topk_select, dim3(B), dim3(1024), 0, st, w.keys2, w.count2, w.sel, p, ep);
