@@ -938,6 +938,10 @@ __device__ __forceinline__ void vx_sweep_async(vx_async_smem_t<MAXTILES> &S, voi
 //   s_setprio 3 on the chain wave: 0.647 / 0.622 / 0.608 (no effect: the workgroup is bound by its instruction count,
 //     the appliers' trips are 60 % of it, not by the chain's latency)
 //   kept boxes of a trip by v_readlane out of the wave's registers instead of LDS reads: 0.800 / 0.749 / 0.725
+//   pair-dense visits (the (kept box, live box) pairs of a visit dealt 64 per step to the lanes through two small
+//     per-wave index lists in LDS, one test per lane: 83 % useful lane-tests instead of ~30 %): 0.618 / 0.615 / 0.655 --
+//     a step costs ~40 instructions (index arithmetic, six per-lane LDS reads) for 64 tests against ~100 for a trip of
+//     256 lane-tests, so the instruction count of an applier wave only falls from ~65 k to ~53 k
 #define VX_SP_CELLS 256
 
 struct vx_spatial_smem {
