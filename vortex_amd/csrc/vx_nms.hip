@@ -942,6 +942,9 @@ __device__ __forceinline__ void vx_sweep_async(vx_async_smem_t<MAXTILES> &S, voi
 //     per-wave index lists in LDS, one test per lane: 83 % useful lane-tests instead of ~30 %): 0.618 / 0.615 / 0.655 --
 //     a step costs ~40 instructions (index arithmetic, six per-lane LDS reads) for 64 tests against ~100 for a trip of
 //     256 lane-tests, so the instruction count of an applier wave only falls from ~65 k to ~53 k
+//   candidate test of two kept boxes per packed fp32 instruction (v_pk_add / v_pk_mul / v_pk_fma_f32; min/max have
+//     no packed form): 35 instead of 51 VALU instructions per trip on paper, 0.672 / 0.615 / 0.609 measured (the
+//     register-pair shuffling around the packed operands eats the saving)
 #define VX_SP_CELLS 256
 
 struct vx_spatial_smem {
