@@ -363,6 +363,39 @@ def test_fused_equals_unfused_and_oracle(sthr, ithr):
         same(fused[b], c.det[b, :k].cpu()[keep])
 
 
+@pytest.mark.parametrize("seed,sthr", [(101, 0.9), (102, 0.5), (103, 0.06), (104, 0.3), (105, 0.7), (106, 0.02)])
+def test_fused_candidates_vs_oracle_any_seed(seed, sthr):
+    """The fused decoder's sigmoid is v_exp/v_rcp based (1e-5 class), so a row whose objectness sits within 1e-6 of the
+    threshold may fall on either side, and a row whose two best class probabilities are within 1e-6 may pick either
+    class.  Instead of choosing a seed without such rows, this test allows exactly those differences: every other row
+    must be there, in row order, with boxes / scores within 1e-5 and the class exact."""
+    S, C, B = 416, 80, 2
+    heads = O.synth_yolo_heads(B, S, C, seed=seed)
+    pred = O.yolo_head_eval(heads, S)
+    c = ops.yolo_fused_decode([h.to(DEV) for h in heads], S, sthr)
+    counts = c.counts.cpu().tolist()
+    for b in range(B):
+        obj = pred[b, :, 4]
+        sure = obj > sthr + 1e-6
+        maybe = (obj - sthr).abs() <= 1e-6
+        rows = torch.nonzero(sure | maybe).squeeze(1)
+        bb, sc, ci, det = O.yolo_decoder(pred[b:b + 1, rows], torch.tensor([-1.0]), S)      # decode all of them
+        top2 = pred[b, rows, 5:].topk(2, dim=1).values
+        cls_tie = (top2[:, 0] - top2[:, 1]) <= 1e-6
+        k = counts[b]
+        gb, gs, gc = c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu()
+        j = 0
+        for i in range(rows.numel()):
+            hit = j < k and torch.allclose(gb[j], bb[i], rtol=1e-5, atol=1e-6)
+            if hit:
+                assert abs(float(gs[j]) - float(sc[i])) <= 1e-5 * max(1.0, abs(float(sc[i])))
+                assert int(gc[j]) == int(ci[i]) or bool(cls_tie[i])
+                j += 1
+            else:
+                assert bool(maybe[rows[i]]), ("row %d missing on the GPU" % int(rows[i]))
+        assert j == k, "the GPU kept rows the oracle does not have"
+
+
 # ------------------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("L,NL,P,B,sthr", [(5, 2, 50400, 2, 0.5), (0, 21, 50400, 2, 0.3), (0, 21, 1000, 3, 0.0), (5, 2, 777, 1, 0.02)])
 def test_prior_decode_and_postprocess(L, NL, P, B, sthr):
