@@ -23,6 +23,9 @@ struct vx_head_params {
     long long out_batch_stride, row_offset;
 };
 
+// A/B (round 2, MI355X, bench.py --unfused, average of the three launches; baseline 0.134 ms): 128-cell tiles (512-B runs
+// per channel plane, 43 KiB of LDS) 0.181 ms; two 64-cell tiles per workgroup with the loads of the second in flight
+// behind the copy-out of the first 0.143 ms.
 template <bool VEC>
 __global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__restrict__ in,
                                                              float *__restrict__ out, vx_head_params p) {
