@@ -682,11 +682,21 @@ __global__ __launch_bounds__(256) void vx_k_cand_finish(const vx_rec *__restrict
             int ci = __float_as_int(r.b.z);
             cls[dst] = (long long)ci;
             float *d = det + dst * p.D;
-            d[0] = r.a.x; d[1] = r.a.y; d[2] = r.a.z; d[3] = r.a.w;
-            d[4] = r.b.y; d[5] = (float)ci;
-            if (p.L > 0) {
-                const float *lm = stage_lmk + src * (2 * p.L);
-                for (int q = 0; q < 2 * p.L; ++q) d[6 + q] = lm[q];
+            if (((p.D & 1) | (int)((uintptr_t)det & 7)) == 0) {
+                // rows of an even number of floats: 8-byte stores (a 24-byte row = 3 stores instead of 6)
+                float2 *d2 = reinterpret_cast<float2 *>(d);
+                d2[0] = make_float2(r.a.x, r.a.y); d2[1] = make_float2(r.a.z, r.a.w); d2[2] = make_float2(r.b.y, (float)ci);
+                if (p.L > 0) {
+                    const float2 *lm = reinterpret_cast<const float2 *>(stage_lmk + src * (2 * p.L));   // 8*L bytes per row
+                    for (int q = 0; q < p.L; ++q) d2[3 + q] = lm[q];
+                }
+            } else {
+                d[0] = r.a.x; d[1] = r.a.y; d[2] = r.a.z; d[3] = r.a.w;
+                d[4] = r.b.y; d[5] = (float)ci;
+                if (p.L > 0) {
+                    const float *lm = stage_lmk + src * (2 * p.L);
+                    for (int q = 0; q < 2 * p.L; ++q) d[6 + q] = lm[q];
+                }
             }
         }
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[b] = running + total;
