@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the normalize kernel alone (development A/B).  usage: ab_norm.py [S] [B]"""
+"""K1 alone at the BASELINE image sizes: kernel time and fraction of 8 TB/s (3 B read + 12 B written per pixel)."""
 import os
 import sys
 
@@ -7,21 +7,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import vortex_amd as V  # noqa: E402
-from vortex_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 416
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device=dev)
-norm = V.Normalize().to(dev)
-for _ in range(5):
-    norm(img)
-torch.cuda.synchronize()
-L.profile_enable(200)
-for _ in range(100):
-    norm(img)
-torch.cuda.synchronize()
-k = L.profile_read()["vx_k_normalize/resize"]
-gb = B * S * S * 15 / 1e9
-print("normalize S=%d B=%d variant %s: avg %.4f ms  min %.4f ms  -> %.0f GB/s avg, %.0f GB/s best" % (
-    S, B, os.environ.get("VX_NORM_VARIANT", "-"), k["avg_ms"], k["min_ms"], gb / k["avg_ms"] * 1e3, gb / k["min_ms"] * 1e3))
+norm = V.Normalize([0.5] * 3, [0.5] * 3).to(dev)
+for B, S in ((256, 416), (128, 640), (64, 640), (64, 512), (32, 608)):
+    img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device=dev)
+    for _ in range(5):
+        norm(img)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        norm(img)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 30
+    by = B * S * S * 15
+    print("b%-4d %4d^2  %.4f ms  %.0f GB/s  %.3f of peak" % (B, S, ms, by / ms / 1e6, by / ms / 1e6 / 8000))
