@@ -274,8 +274,51 @@ def nan_case(seed):
     return ok, dict(kind="nan", seed=seed, S=S, C=C, B=B, head=hi, pos=pos)
 
 
+def declared_case(seed):
+    """ops.batched_nms with the class count declared: batches of 1-3 images of different fill, capacities on both sides
+    of the single-launch kernel (so the class-partitioned path, the ordered kept runs + merge rounds, the top-k select,
+    the general path for an oversized class and the optimistic call's deferral all come up)."""
+    g = torch.Generator().manual_seed(90_000 + seed)
+    K = int(torch.randint(200, [3000, 20000, 45000][seed % 3], (1,), generator=g))
+    C = [4, 7, 20, 80, 256][seed % 5]
+    kind = ["normal", "grid", "dup", "inverted"][(seed // 3) % 4]
+    if kind in ("dup", "grid"):
+        K = min(K, 9000)
+    B = 1 + seed % 3
+    top_k = [None, 100, 2048, 2049, 6000][(seed // 2) % 5]
+    thr = [0.2, 0.45, 0.5, 0.7][seed % 4]
+    optimistic = K > ops.NMS_SINGLE_LAUNCH_MAX and seed % 2 == 0
+    boxes = torch.stack([_boxes(kind, K, g) for _ in range(B)]).contiguous()
+    scores = torch.rand(B, K, generator=g)
+    if seed % 4 == 1:
+        scores = (scores * 32).floor() / 32
+    cls = torch.randint(0, C, (B, K), generator=g)
+    if seed % 7 == 0:
+        cls[0, : int(K * 0.7)] = C - 1
+    counts = torch.tensor([K if b == 0 else int(torch.randint(0, K + 1, (1,), generator=g)) for b in range(B)], dtype=torch.int32)
+    det = torch.cat((boxes, scores[..., None], cls[..., None].float()), 2)
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV),
+                                                             counts.to(DEV), thr, n_classes=C, top_k=top_k, optimistic=optimistic)
+    st = int(status.item())
+    deferred = bool(st & V._lib.VX_STATUS_DEFERRED)
+    ok = ops.status_ok(st & ~V._lib.VX_STATUS_DEFERRED)
+    if deferred:                                          # only an image with one class beyond 16384 candidates may be deferred
+        ok = ok and optimistic and any(int(torch.bincount(cls[b, :int(counts[b])], minlength=C).max()) > 16384 for b in range(B))
+        keep_idx, out_det, keep_counts, status = ops.batched_nms(boxes.to(DEV), scores.to(DEV), cls.to(DEV), det.to(DEV),
+                                                                 counts.to(DEV), thr, n_classes=C, top_k=top_k)
+        ok = ok and ops.status_ok(int(status.item()))
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([thr]))
+        if top_k:
+            ref = ref[:top_k]
+        kc = int(keep_counts[b].item())
+        ok = ok and kc == ref.numel() and torch.equal(keep_idx[b, :kc].cpu(), ref) and torch.equal(out_det[b, :kc].cpu(), det[b, ref])
+    return ok, dict(kind="declared", seed=seed, K=K, C=C, B=B, box=kind, thr=thr, top_k=top_k, optimistic=optimistic)
+
+
 CASES = (nms_case, ragged_case, yolo_case, prior_case, pre_case, layer_case, format_case, detr_case, nan_case,
-         nms_case, layer_case)
+         nms_case, layer_case, declared_case, declared_case)
 
 
 if __name__ == "__main__":
