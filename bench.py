@@ -90,6 +90,30 @@ def cpu_baseline(sthr, ithr, budget_s=15.0, n_img=8):
                       "iterations on 1 thread, %.0f s)" % (n, n_img, sthr, ithr, dt, n1, dt1)}
 
 
+def count_gpus_without_hip():
+    """GPUs visible to the ranks, counted WITHOUT touching torch.cuda / HIP in this launcher process (on ROCm
+    torch.cuda.device_count() can fall through to hipGetDeviceCount, which initialises the runtime in the parent the
+    rank processes are then started from): the KFD topology lists one node per agent, GPUs are those with SIMDs; the
+    visibility variables narrow that."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                pass
+    except OSError:
+        return 0
+    return n
+
+
 def spawn_ranks(n, argv):
     """Self-contained multi-GPU launch: N fresh worker processes (this process never initialises a GPU), one rank
     per GPU, rendezvous on 127.0.0.1.  Fewer GPUs than ranks -> gloo backend, ranks share GPUs (rehearsal only)."""
@@ -98,7 +122,7 @@ def spawn_ranks(n, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    ndev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    ndev = count_gpus_without_hip()
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",

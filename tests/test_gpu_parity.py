@@ -348,15 +348,20 @@ def test_fused_equals_unfused_and_oracle(sthr, ithr):
         same(c0.cls[b, :k], c1.cls[b, :k]); same(c0.det[b, :k], c1.det[b, :k])
     # candidates vs oracle
     pred = O.yolo_head_eval(heads, S)
-    assert float((pred[..., 4] - sthr).abs().min()) > 1e-6     # no borderline objectness in this seed
     c = ops.yolo_fused_decode(dheads, S, sthr)
     counts = c.counts.cpu().tolist()
     for b in range(B):
         bb, sc, ci, det = O.yolo_decoder(pred[b:b + 1], torch.tensor([sthr]), S)
         k = counts[b]
-        assert k == bb.shape[0]
-        close(c.boxes[b, :k], bb); close(c.scores[b, :k], sc); close(c.det[b, :k, :5], det[0, :, :5])
-        same(c.cls[b, :k], ci)
+        # an image with an objectness within 1e-6 of the threshold, or with its two best class probabilities that close,
+        # may legitimately differ in a row (v_exp/v_rcp sigmoid): test_fused_candidates_vs_oracle_any_seed
+        # covers those rows with its allowance; images without such a row must agree row for row
+        top2 = pred[b, pred[b, :, 4] > sthr - 1e-6, 5:].topk(2, dim=1).values
+        borderline = bool(((pred[b, :, 4] - sthr).abs() <= 1e-6).any()) or bool(((top2[:, 0] - top2[:, 1]) <= 1e-6).any())
+        if not borderline:
+            assert k == bb.shape[0]
+            close(c.boxes[b, :k], bb); close(c.scores[b, :k], sc); close(c.det[b, :k, :5], det[0, :, :5])
+            same(c.cls[b, :k], ci)
         # NMS from identical inputs: bit-exact keep
         gb, gs, gc = c.boxes[b, :k].cpu(), c.scores[b, :k].cpu(), c.cls[b, :k].cpu()
         keep = O.batched_nms(gb, gs, gc, torch.tensor([ithr]))

@@ -1,10 +1,11 @@
 """vx_batched_nms_noalloc (the allocation-free entry point: static device scratch, no hipMalloc) against
-vx_batched_nms through the C ABI: bit-identical keep indices, counts, gathered rows and status on two calls in
-a row, the second one with a smaller input (the shared scratch keeps the first call's contents).
+vx_batched_nms through the C ABI AND against the oracle: bit-identical keep indices, counts, gathered rows and status
+on two calls in a row, the second one with a smaller input (the shared scratch keeps the first call's contents).
 Collected last (test_zz_*): it must pass alone in a fresh process and after every other test."""
 import pytest
 import torch
 
+from oracle import vortex_oracle as O
 from vortex_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
@@ -66,6 +67,23 @@ def _same(a, b):
         assert torch.equal(da[i, :n], db[i, :n]), "gathered rows differ in image %d" % i
 
 
+def _same_as_oracle(got, inp, thr, top_k):
+    """keep indices and gathered rows of every image against oracle.batched_nms (reference nms.py:57-98,105-123 with the
+    oracle's greedy core) on the image's first counts[b] candidates; top_k = the first k of the keep list."""
+    boxes, scores, cls, det, counts = [t.cpu() if t is not None else None for t in inp]
+    keep_idx, out_det, keep_counts, status = got
+    assert status & ~(L.VX_STATUS_RANGE | L.VX_STATUS_RANGE2) == 0
+    for b in range(scores.shape[0]):
+        n = int(counts[b]) if counts is not None else scores.shape[1]
+        keep = O.batched_nms(boxes[b, :n], scores[b, :n], cls[b, :n], torch.tensor([thr]))
+        if top_k:
+            keep = keep[:top_k]
+        k = int(keep_counts[b])
+        assert k == keep.numel(), "image %d: %d kept, oracle %d" % (b, k, keep.numel())
+        assert torch.equal(keep_idx[b, :k], keep), "keep indices differ from the oracle in image %d" % b
+        assert torch.equal(out_det[b, :k], det[b][keep]), "gathered rows differ from the oracle in image %d" % b
+
+
 @pytest.mark.parametrize("shapes", [
     # (B, K, classes, top_k): first call, then a smaller one
     [(8, 3000, 20, 0), (3, 700, 20, 0)],                 # single-launch kernel
@@ -79,6 +97,7 @@ def test_noalloc_matches_batched_nms_two_calls(shapes):
         got = _call(True, *inp, C, 0.45, top_k)
         assert int(ref[2].sum()) > 0
         _same(got, ref)
+        _same_as_oracle(got, inp, 0.45, top_k)
 
 
 def test_noalloc_rejects_oversized_calls_and_allocates_nothing():

@@ -2,6 +2,7 @@
 // each wave holds NT column tiles (64 boxes each) in registers and applies KC kept boxes (LDS) to them, REP times.
 // Prints shader cycles per wave-level IoU test for several formulations of the loop body, so the sweep kernels can
 // be shaped by measurement:  ./sweep_loop [grid]
+// build (the binary is not tracked):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/sweep_loop.hip -o tools/micro/sweep_loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple, Union
 import torch
 
 from . import ops
-from .postprocess import PendingDetections, _f
+from .postprocess import PendingDetections, _f, mirror_is_coherent
 
 
 class _Captured:
@@ -41,6 +41,11 @@ class GraphedPostProcess:
         first = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
         self.device = first.device
         self.preprocessed = None
+        # Decided BEFORE warm-up and capture: the check allocates and waits on an event, neither of which may happen
+        # inside a capture (the first mirror_is_coherent call of a process must therefore be outside any user capture
+        # too).  When kernel stores to pinned memory are not host-visible, the chain captures a D2H copy of the
+        # meta words instead of the kernel-side mirror -- the same fallback the eager path takes.
+        self._coherent = mirror_is_coherent(self.device)
         self._n = 0
         self._sets = []
         side = torch.cuda.Stream(self.device)
@@ -65,7 +70,11 @@ class GraphedPostProcess:
     def _chain(self, host):
         x = self.preprocess(self.images) if (self.preprocess is not None and self.images is not None) else None
         out_det, keep_counts, meta = self.post.forward_unpacked(self.inputs, self._sthr, self._ithr)
-        packed = ops.pack_rows(out_det, keep_counts, meta, host)
+        if self._coherent:
+            packed = ops.pack_rows(out_det, keep_counts, meta, host)
+        else:
+            packed = ops.pack_rows(out_det, keep_counts)
+            host.copy_(meta, non_blocking=True)
         return x, packed, meta
 
     def launch(self) -> PendingDetections:

@@ -11,7 +11,8 @@ that composes whatever pre-process / network / post-process modules it is given,
   get_prediction_results  host-side column slicing with the contract of reference predictor/utils.py:11-33
                         (np.take per output_format key, None for an empty result)
 
-`BasePredictor` is kept as an alias of Pipeline so existing imports keep working."""
+`BasePredictor` keeps the reference's constructor contract on top of Pipeline (see the class), so code that imports
+the name gets the reference's checks and defaults, not a look-alike."""
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
@@ -23,9 +24,12 @@ import torch.nn as nn
 class Pipeline(nn.Module):
     def __init__(self, model: nn.Module, preprocess: Optional[nn.Module] = None, postprocess: Optional[nn.Module] = None):
         super().__init__()
+        from .postprocess import NoOpPostProcess
         self.preprocess = preprocess if preprocess is not None else nn.Identity()
         self.model = model
-        self.postprocess = postprocess
+        # no post-process given -> the pass-through module, as the reference (predictor/base_module.py:45-46):
+        # forward() and detect() then share one path
+        self.postprocess = postprocess if postprocess is not None else NoOpPostProcess()
         # the column map of the result rows travels with the network (reference models/detection/yolov3.py:56-60)
         self.output_format = dict(getattr(model, "output_format", {}))
         self.task = getattr(model, "task", "detection")
@@ -33,8 +37,7 @@ class Pipeline(nn.Module):
 
     @torch.no_grad()
     def forward(self, input: torch.Tensor, *args, **kwargs):
-        x = self.model(self.preprocess(input))
-        return x if self.postprocess is None else self.postprocess(x, *args, **kwargs)
+        return self.postprocess(self.model(self.preprocess(input)), *args, **kwargs)
 
     def detect(self, input: torch.Tensor, *args, image_sizes: Optional[Sequence] = None, **kwargs) -> List[Dict[str, np.ndarray]]:
         """forward() + the reference's result dictionaries; with `image_sizes` (images or (h, w) sizes) the coordinates come back in
@@ -49,15 +52,55 @@ class Pipeline(nn.Module):
         return get_prediction_results(self.postprocess(x, *args, **kwargs), self.output_format)
 
 
-BasePredictor = Pipeline
+_REQUIRED_KEYS = {"detection": ("bounding_box", "class_confidence"), "classification": ("class_label", "class_confidence")}
 
 
-def create_predictor(model_components, **kwargs) -> Pipeline:
+class BasePredictor(Pipeline):
+    """Pipeline under the reference's constructor contract (predictor/base_module.py:37-102):
+      * the network must carry `task` ("detection" | "classification", anything else is a RuntimeError) and
+        `output_format` (AssertionError when missing) holding the keys the task requires (RuntimeError otherwise);
+      * a pre-process other than nn.Identity and a post-process other than NoOpPostProcess must have an annotated
+        `forward` (RuntimeError); the pre-process annotations must read input: Tensor -> Tensor (TypeError);
+      * `postprocess=None` means NoOpPostProcess, `preprocess=None` means nn.Identity;
+      * forward() runs under the caller's grad mode (Pipeline wraps it in no_grad; the reference does not)."""
+
+    def __init__(self, model: nn.Module, preprocess: Optional[nn.Module] = None, postprocess: Optional[nn.Module] = None):
+        from .postprocess import NoOpPostProcess
+        if not hasattr(model, "task"):
+            raise AttributeError("model definition '%s' has no 'task' attribute" % type(model).__name__)
+        assert hasattr(model, "output_format"), \
+            "model definition '%s' doesn't have 'output_format' attribute" % type(model)
+        super().__init__(model, preprocess, postprocess)
+        self.task = model.task
+        if type(self.postprocess) is not NoOpPostProcess and not getattr(self.postprocess.forward, "__annotations__", None):
+            raise RuntimeError("please annotate postprocess with %s" % ["input", "return"])
+        if type(self.preprocess) is not nn.Identity:
+            ann = getattr(self.preprocess.forward, "__annotations__", None)
+            if not ann:
+                raise RuntimeError("please annotate preprocess with %s" % ["input", "return"])
+            for key in ("input", "return"):
+                if key not in ann:
+                    raise TypeError("missing preprocess annotation(s) : %s" % key)
+                if ann[key] != torch.Tensor:
+                    raise TypeError("type mismatch for `%s`, expects %s got %s" % (key, torch.Tensor, ann[key]))
+        if self.task not in _REQUIRED_KEYS:
+            raise RuntimeError("unknown task of '%s'" % self.task)
+        for key in _REQUIRED_KEYS[self.task]:
+            if key not in self.output_format:
+                raise RuntimeError("expects output_format for task %s to have `%s` key, got output_format: %s"
+                                   % (self.task, key, self.output_format))
+
+    def forward(self, input: torch.Tensor, *args, **kwargs):
+        return self.postprocess(self.model(self.preprocess(input)), *args, **kwargs)
+
+
+def create_predictor(model_components, **kwargs) -> BasePredictor:
+    """reference predictor/base_module.py:105-113: components -> BasePredictor (with its checks)."""
     def pick(name):
         if isinstance(model_components, dict):
             return model_components.get(name)
         return getattr(model_components, name, None)
-    return Pipeline(pick("network"), preprocess=pick("preprocess"), postprocess=pick("postprocess"))
+    return BasePredictor(pick("network"), preprocess=pick("preprocess"), postprocess=pick("postprocess"))
 
 
 def _columns(spec) -> List[int]:
