@@ -303,6 +303,9 @@ int vx_profile_set_iou_counter(uint64_t *d_counter);
  * per wave of the image's last column-owner sweep, cycles spent waiting / applying / on the chain / building rows,
  * total cycles and IoU tests. */
 size_t vx_batched_nms_stamps_offset(int B, int capacity);
+/* Diagnostics of the bitmask NMS path (capacity > 16384): byte offset, inside the NMS workspace, of its int[64] counter
+ * block ([0] large segments registered, [1] work items; [8..13] only in a -DVX_BM_DEBUG build); 0 = no such path. */
+size_t vx_batched_nms_bm_counters_offset(int B, int capacity);
 
 #ifdef __cplusplus
 }

@@ -110,7 +110,8 @@ def _roof(kernel, ms, algo_bytes, tag=None, pmc_kernel=None):
                               "not collected (PMC passes are separate rocprofv3 runs: profiles/)"}
 
 
-NMS_KERNELS = ("vx_k_nms_image", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather", "vx_k_nms_sweep", "vx_k_sort(keys2)+output")
+NMS_KERNELS = ("vx_k_nms_image", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather", "vx_k_nms_sweep", "vx_k_sort(keys2)+output",
+               "vx_k_bm_pairs", "vx_k_bm_finish/scan")
 
 
 def _cpu(fn, images, budget_s, what):

@@ -41,6 +41,11 @@ for it in range(3):
     assert rc == 0
 torch.cuda.synchronize()
 print({k: round(v["avg_ms"], 4) for k, v in L.profile_read().items()})
+boff = lib.vx_batched_nms_bm_counters_offset(B, K)
+if boff:
+    cw = ws[boff:boff + 256].view(torch.int32).cpu().tolist()
+    print("bitmask path: segments %d, work items %d; debug [items, tile pairs, visits, trips, hit boxes, edges] = %s"
+          % (cw[0], cw[1], cw[8:14]))
 off = lib.vx_batched_nms_stamps_offset(B, K)
 SW = 136
 allw = ws[off:off + B * SW * 8].view(torch.int64).view(B, SW).cpu().double()

@@ -35,7 +35,7 @@ const char *g_names[VX_PROF_NSLOTS] = {
     "vx_k_normalize/resize", "vx_k_yolo_head_decode", "vx_k_yolo_decode_rows", "vx_k_yolo_fused",
     "vx_k_cand_finish", "vx_k_prior_decode", "vx_k_nms_build_keys", "vx_k_sort(keys1)+gather",
     "vx_k_nms_sweep", "vx_k_sort(keys2)+output", "vx_k_pack_rows", "vx_k_nms_image",
-    "vx_k_detr_decode", "vx_k_softmax_max"};
+    "vx_k_detr_decode", "vx_k_softmax_max", "vx_k_bm_pairs", "vx_k_bm_finish/scan"};
 }  // namespace
 
 void vx_prof_begin_impl(int slot, hipStream_t st) {

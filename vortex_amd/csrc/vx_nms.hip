@@ -1247,6 +1247,8 @@ __device__ __forceinline__ void vx_async_emit(const vx_async_smem_t<MAXTILES> &S
     vx_masks_emit(S.alive, S.ndone, keys, keys2, count2, kcount);
 }
 
+#include "vx_nms_bm.h"
+
 __global__ __launch_bounds__(1024) void vx_k_nms_sweep(const u64 *__restrict__ keys1, const vx_f4 *__restrict__ sbox,
                                                       const float *__restrict__ sarea,
                                                       const int *__restrict__ counts, vx_nms_params p,
@@ -1333,6 +1335,8 @@ struct vx_part_args {
     int *keep_counts;
     int ordered;           // 1: the kept keys of class c go, in order, to keys2[segstart[c]..) and their number to
                            //    hist[b][c] (the run merge below takes them from there); 0: keys2 through count2
+    vx_bm_ws bm;           // bitmask path (vx_nms_bm.h): large segments are exported instead of swept when bm_on != 0
+    int bm_on;
 };
 
 __device__ __forceinline__ int vx_part_class(long long c, int n_classes, bool &bad) {
@@ -1428,7 +1432,8 @@ template <int LDS_KEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
-    __shared__ vx_spatial_smem SP;
+    __shared__ union { vx_spatial_smem sp; vx_bm_prep_smem prep; } U;
+    vx_spatial_smem &SP = U.sp;
     __shared__ int s_rbits;
     const int b = blockIdx.y, c = blockIdx.x;
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
@@ -1469,6 +1474,8 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     int *kc = a.ordered ? a.hist + b * VX_PART_MAX_CLASSES + c : nullptr;     // the histogram has been consumed
     if (!big) {
         if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count, kc);
+    } else if (a.bm_on && T.fast && len > VX_BM_MIN && vx_bm_prep(U.prep, a.bm, b, lo, c, 1, sb, len)) {
+        // registered for vx_k_bm_pairs; vx_k_bm_scan emits the kept keys
     } else if (vx_sweep_spatial(SP, sk, (size_t)(LDS_KEYS > VX_PART_SMALL ? VX_SORT_CHMAX * 8 : VX_PART_SMALL * 20), sb, len, T, p.top_k, a.iou_count)) {
         vx_spatial_emit(SP, kseg, k2, c2, kc);
     } else {
@@ -1476,6 +1483,34 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
         vx_async_emit(A, kseg, k2, c2, kc);
     }
     if (threadIdx.x == 0) vx_status_or(a.status, s_rbits);
+}
+
+// Bitmask path, last step on the class-partitioned route: the registered segments are dealt round-robin to the
+// workgroups; each is resolved from its edge list (the chain sweep when the list overflowed) and its kept keys are
+// emitted exactly as vx_k_part_sweep would have done.
+__global__ __launch_bounds__(256) void vx_k_bm_scan(vx_part_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];             // ring of the chain sweep (fallback only)
+    __shared__ union { vx_async_smem as; vx_bm_scan_smem sc; } U;
+    const vx_nms_params &p = a.p;
+    const int nsegs = min(a.bm.counters[0], a.bm.max_segs);
+    const vx_thr T = vx_make_thr(p.thr);
+    for (int si = blockIdx.x; si < nsegs; si += gridDim.x) {
+        const vx_bm_seg sg = a.bm.segs[si];
+        if (sg.route != 1) continue;
+        const int b = sg.b, c = sg.id;
+        const long long ob = (long long)b * p.npad_cap, region = ob + sg.lo;
+        const u64 *kseg = a.keys1 + region;
+        u64 *k2 = a.keys2 + ob + (a.ordered ? sg.lo : 0);
+        int *c2 = a.count2 + b;
+        int *kc = a.ordered ? a.hist + b * VX_PART_MAX_CLASSES + c : nullptr;
+        if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
+                       sg.len * VX_BM_ECAP, sg.len, p.top_k)) {
+            vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, k2, c2, kc);
+        } else {
+            vx_sweep_async(U.as, sk, a.sbox + region, sg.len, T, p.top_k, a.iou_count);
+            vx_async_emit(U.as, kseg, k2, c2, kc);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1706,6 +1741,8 @@ struct vx_image_args {
     size_t lds_bytes; // dynamic LDS of the launch
     int defer;        // != 0: such images are only reported (VX_STATUS_DEFERRED, keep_count 0), nobody finishes them
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
+    vx_bm_ws bm;      // bitmask path (vx_nms_bm.h): large segments are exported instead of swept here when bm_on != 0
+    int bm_on;
 };
 
 // An image with <= 64 candidates (the common case at the shipped score threshold 0.9: ~10 per image) is one
@@ -1786,146 +1823,18 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
 }
 
 #define VX_IMG_MERGE_PER_THREAD 8        // positions of the run merge whose run index a thread keeps in registers
-__global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
-    extern __shared__ __attribute__((aligned(16))) u64 sk[];
-    __shared__ vx_async_smem A;
-    __shared__ vx_spatial_smem SP;
-    __shared__ int s_big[VX_SWEEP_MAXBIG][3];
-    __shared__ int s_nbig, s_count2, s_nseg, s_rbits;
-    __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
-    __shared__ u64 s_wmask[16][64];
-    __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
+// Tail of the single-launch kernel (also run by vx_k_bm_finish for an image whose large segments went through the
+// bitmask path): the kept keys of all segments -> global score order (run merge in LDS, or a second sort) -> outputs.
+__device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int n, int nseg, bool merge, u64 *sk,
+                                              int *s_gcnt, int *s_count2p, int rbits) {
     const vx_nms_params &p = a.p;
-    const int b = blockIdx.x, nt = blockDim.x;
-    const int n = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
-    if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
-        const bool big = n > a.n_max;
-        if (threadIdx.x == 0) {
-            a.sel[b] = big ? n : 0;
-            if (big && a.defer) { atomicOr(a.status, VX_STATUS_DEFERRED); a.keep_counts[b] = 0; }
-        }
-        if (big) return;
-    }
-    if (n == 0) {
-        if (threadIdx.x == 0) a.keep_counts[b] = 0;
-        return;
-    }
-    if (n <= 64) {                                   // before any barrier: waves 1.. leave, wave 0 needs none
-        if (threadIdx.x < 64) vx_nms_image_small(a, b, n);
-        return;
-    }
-    const int npad = vx_next_pow2(n);
+    const int nt = blockDim.x, wave = threadIdx.x >> 6, lane = vx_lane();
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
-#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + (k)] = clock64(); } while (0)
-    VX_STAMP(0);
-    bool bad = false;
-    for (int i = threadIdx.x; i < npad; i += nt) {
-        u64 key = VX_KEY_SENTINEL;
-        if (i < n) {
-            long long c = a.cls[ib + i];
-            if (c < 0 || c >= p.n_classes) { bad = true; c = c < 0 ? 0 : p.n_classes - 1; }
-            key = vx_key1((int)c, a.scores[ib + i], i);
-        }
-        sk[i] = key;
-    }
-    if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
-    if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; s_rbits = 0; }
-    vx_build_pair_lut(s_pair_lut);
-    __syncthreads();
-    VX_STAMP(1);
-    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
-    VX_STAMP(2);
-    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
-    vx_f4 *sb = a.sbox + ob;
-    float *sa = a.sarea + ob;
-    u64 *kg = a.keys1 + ob;
-    int oob = 0;
-    for (int i = threadIdx.x; i < n; i += nt) {
-        u64 key = sk[i];
-        kg[i] = key;
-        float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
-        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
-        oob |= vx_range_bits(bx);
-        bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
-        sb[i] = bx;
-        sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
-    }
-    if (p.n_classes != 1) vx_flag_range_lds(oob, &s_rbits);
-    __syncthreads();
-    VX_STAMP(3);
     u64 *k2 = a.keys2 + ob;
-    const vx_thr T = vx_make_thr(p.thr);
-    const int wave = threadIdx.x >> 6, nw = nt >> 6, lane = vx_lane();
-    // ordered list of class-segment starts: boundary flags -> per-64-group counts -> scan -> scatter
-    int *seg = a.seg + (long long)b * VX_MAX_CLASSES;
-    const int groups = (n + 63) >> 6;
-    for (int g = wave; g < groups; g += nw) {
-        int i = g * 64 + lane;
-        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
-        u64 m = __ballot(flag);
-        if (lane == 0) s_gcnt[g] = __popcll(m);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        int c[4], tot = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; c[q] = g < groups ? s_gcnt[g] : 0; tot += c[q]; }
-        int incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-        int run = incl - tot;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; if (g < groups) s_gcnt[g] = run; run += c[q]; }
-        if (lane == 63) s_nseg = incl;
-    }
-    __syncthreads();
-    for (int g = wave; g < groups; g += nw) {
-        int i = g * 64 + lane;
-        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
-        u64 m = __ballot(flag);
-        if (flag) seg[s_gcnt[g] + vx_mbcnt(m)] = i;
-    }
-    __syncthreads();
-    const int nseg = s_nseg;
-    // Kept keys: every segment writes its kept keys IN ORDER to k2[lo ..] and their number to segk[s]; the runs are then
-    // merged in LDS (ceil(log2 nseg) rounds, one binary search per key) -- a fraction of the work of a second bitonic
-    // sort.  Needs two key buffers + the run boundaries in the launch's LDS; otherwise (or with one segment beyond
-    // the list) the kept keys go through the image's counter and are sorted.
-    const bool merge = nseg <= VX_MAX_CLASSES && n <= VX_IMG_MERGE_PER_THREAD * nt &&
-                       ((size_t)2 * n * sizeof(u64) + (size_t)(nseg + 1) * sizeof(int)) <= a.lds_bytes;
-    int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
-    for (int s = wave; s < nseg; s += nw) {
-        int lo = seg[s];
-        int hi = s + 1 < nseg ? seg[s + 1] : n;
-        int len = hi - lo;
-        if (len <= 64) {
-            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, merge ? k2 + lo : k2, &s_count2, a.iou_count,
-                           merge ? segk + s : nullptr);
-        } else if (len <= 64 * VX_SWEEP_WT) {
-            vx_sweep_wave(sb, sa, sk, lo, len, T, merge ? k2 + lo : k2, &s_count2, a.iou_count, merge ? segk + s : nullptr);
-        } else if (lane == 0) {
-            int q = atomicAdd(&s_nbig, 1);
-            if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; s_big[q][2] = s; }
-        }
-    }
-    __syncthreads();
-    VX_STAMP(4);
-    // large segments, the whole workgroup each (chain sweep; its kept-box ring takes the keys' LDS -- the sorted keys
-    // live on in kg)
-    const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
-    for (int q = 0; q < nbig; ++q) {
-        const int lo = s_big[q][0], len = s_big[q][1];
-        int *kc = merge ? segk + s_big[q][2] : nullptr;
-        u64 *kd = merge ? k2 + lo : k2;
-        if (vx_sweep_spatial(SP, sk, a.lds_bytes, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr)) {
-            vx_spatial_emit(SP, kg + lo, kd, &s_count2, kc);
-        } else {
-            vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
-            vx_async_emit(A, kg + lo, kd, &s_count2, kc);
-        }
-    }
-    __syncthreads();
-    VX_STAMP(5);
+    const int *seg = a.seg + (long long)b * VX_MAX_CLASSES;
+    const int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
+    int &s_count2 = *s_count2p;
+#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + (k)] = clock64(); } while (0)
     int n2;
     if (merge) {
         // run boundaries R[0..nseg] = exclusive scan of the kept counts (4 per thread, wave scan, wave totals)
@@ -2011,8 +1920,204 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     }
     __syncthreads();
     VX_STAMP(7);
-    if (threadIdx.x == 0) vx_status_or(a.status, s_rbits);
+    if (threadIdx.x == 0) vx_status_or(a.status, rbits);
 #undef VX_STAMP
+}
+
+__global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    __shared__ vx_async_smem A;
+    __shared__ union { vx_spatial_smem sp; vx_bm_prep_smem prep; } U;      // the spatial sweep and the bitmask prep never overlap
+    vx_spatial_smem &SP = U.sp;
+    __shared__ int s_big[VX_SWEEP_MAXBIG][3];
+    __shared__ int s_nbig, s_count2, s_nseg, s_rbits, s_nexp;
+    __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
+    __shared__ u64 s_wmask[16][64];
+    __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
+    const vx_nms_params &p = a.p;
+    const int b = blockIdx.x, nt = blockDim.x;
+    const int n = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    if (a.bm_on && threadIdx.x == 0) { a.bm.pend[2 * b] = 0; a.bm.pend[2 * b + 1] = 0; }
+    if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
+        const bool big = n > a.n_max;
+        if (threadIdx.x == 0) {
+            a.sel[b] = big ? n : 0;
+            if (big && a.defer) { atomicOr(a.status, VX_STATUS_DEFERRED); a.keep_counts[b] = 0; }
+        }
+        if (big) return;
+    }
+    if (n == 0) {
+        if (threadIdx.x == 0) a.keep_counts[b] = 0;
+        return;
+    }
+    if (n <= 64) {                                   // before any barrier: waves 1.. leave, wave 0 needs none
+        if (threadIdx.x < 64) vx_nms_image_small(a, b, n);
+        return;
+    }
+    const int npad = vx_next_pow2(n);
+    const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
+#define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + (k)] = clock64(); } while (0)
+    VX_STAMP(0);
+    bool bad = false;
+    for (int i = threadIdx.x; i < npad; i += nt) {
+        u64 key = VX_KEY_SENTINEL;
+        if (i < n) {
+            long long c = a.cls[ib + i];
+            if (c < 0 || c >= p.n_classes) { bad = true; c = c < 0 ? 0 : p.n_classes - 1; }
+            key = vx_key1((int)c, a.scores[ib + i], i);
+        }
+        sk[i] = key;
+    }
+    if (__ballot(bad) != 0 && vx_lane() == 0) atomicOr(a.status, VX_STATUS_BAD_CLASS);
+    if (threadIdx.x == 0) { s_nbig = 0; s_count2 = 0; s_rbits = 0; s_nexp = 0; }
+    vx_build_pair_lut(s_pair_lut);
+    __syncthreads();
+    VX_STAMP(1);
+    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    VX_STAMP(2);
+    // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
+    vx_f4 *sb = a.sbox + ob;
+    float *sa = a.sarea + ob;
+    u64 *kg = a.keys1 + ob;
+    int oob = 0;
+    for (int i = threadIdx.x; i < n; i += nt) {
+        u64 key = sk[i];
+        kg[i] = key;
+        float off = (float)(vx_key1_cls(key) * (VX_MAX_COORDINATE + 1));
+        vx_f4 bx = *reinterpret_cast<const vx_f4 *>(a.boxes + (ib + vx_key1_idx(key)) * 4);
+        oob |= vx_range_bits(bx);
+        bx.x = bx.x + off; bx.y = bx.y + off; bx.z = bx.z + off; bx.w = bx.w + off;
+        sb[i] = bx;
+        sa[i] = (bx.z - bx.x) * (bx.w - bx.y);
+    }
+    if (p.n_classes != 1) vx_flag_range_lds(oob, &s_rbits);
+    __syncthreads();
+    VX_STAMP(3);
+    u64 *k2 = a.keys2 + ob;
+    const vx_thr T = vx_make_thr(p.thr);
+    const int wave = threadIdx.x >> 6, nw = nt >> 6, lane = vx_lane();
+    // ordered list of class-segment starts: boundary flags -> per-64-group counts -> scan -> scatter
+    int *seg = a.seg + (long long)b * VX_MAX_CLASSES;
+    const int groups = (n + 63) >> 6;
+    for (int g = wave; g < groups; g += nw) {
+        int i = g * 64 + lane;
+        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
+        u64 m = __ballot(flag);
+        if (lane == 0) s_gcnt[g] = __popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int c[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; c[q] = g < groups ? s_gcnt[g] : 0; tot += c[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; if (g < groups) s_gcnt[g] = run; run += c[q]; }
+        if (lane == 63) s_nseg = incl;
+    }
+    __syncthreads();
+    for (int g = wave; g < groups; g += nw) {
+        int i = g * 64 + lane;
+        bool flag = i < n && (i == 0 || vx_key1_cls(sk[i - 1]) != vx_key1_cls(sk[i]));
+        u64 m = __ballot(flag);
+        if (flag) seg[s_gcnt[g] + vx_mbcnt(m)] = i;
+    }
+    __syncthreads();
+    const int nseg = s_nseg;
+    // Kept keys: every segment writes its kept keys IN ORDER to k2[lo ..] and their number to segk[s]; the runs are then
+    // merged in LDS (ceil(log2 nseg) rounds, one binary search per key) -- a fraction of the work of a second bitonic
+    // sort.  Needs two key buffers + the run boundaries in the launch's LDS; otherwise (or with one segment beyond
+    // the list) the kept keys go through the image's counter and are sorted.
+    const bool merge = nseg <= VX_MAX_CLASSES && n <= VX_IMG_MERGE_PER_THREAD * nt &&
+                       ((size_t)2 * n * sizeof(u64) + (size_t)(nseg + 1) * sizeof(int)) <= a.lds_bytes;
+    int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
+    for (int s = wave; s < nseg; s += nw) {
+        int lo = seg[s];
+        int hi = s + 1 < nseg ? seg[s + 1] : n;
+        int len = hi - lo;
+        if (len <= 64) {
+            vx_sweep_pairs(sb, sa, sk, lo, len, T, s_wmask[wave], s_pair_lut, merge ? k2 + lo : k2, &s_count2, a.iou_count,
+                           merge ? segk + s : nullptr);
+        } else if (len <= 64 * VX_SWEEP_WT) {
+            vx_sweep_wave(sb, sa, sk, lo, len, T, merge ? k2 + lo : k2, &s_count2, a.iou_count, merge ? segk + s : nullptr);
+        } else if (lane == 0) {
+            int q = atomicAdd(&s_nbig, 1);
+            if (q < VX_SWEEP_MAXBIG) { s_big[q][0] = lo; s_big[q][1] = len; s_big[q][2] = s; }
+        }
+    }
+    __syncthreads();
+    VX_STAMP(4);
+    // large segments, the whole workgroup each (chain sweep; its kept-box ring takes the keys' LDS -- the sorted keys
+    // live on in kg)
+    const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
+    // bitmask path: a large tame segment is laid out by position and registered for vx_k_bm_pairs; vx_k_bm_finish then
+    // resolves it from its edge list and runs this kernel's tail for the image (needs the ordered-run bookkeeping)
+    const bool bm_ok = a.bm_on && merge && T.fast;
+    for (int q = 0; q < nbig; ++q) {
+        const int lo = s_big[q][0], len = s_big[q][1];
+        int *kc = merge ? segk + s_big[q][2] : nullptr;
+        u64 *kd = merge ? k2 + lo : k2;
+        if (bm_ok && len > VX_BM_MIN && len <= VX_BM_MAXN && vx_bm_prep(U.prep, a.bm, b, lo, s_big[q][2], 0, sb + lo, len)) {
+            if (threadIdx.x == 0) { a.bm.img_exp[b * VX_BM_MAXEXP + s_nexp] = U.prep.si; ++s_nexp; }
+            continue;
+        }
+        if (vx_sweep_spatial(SP, sk, a.lds_bytes, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr)) {
+            vx_spatial_emit(SP, kg + lo, kd, &s_count2, kc);
+        } else {
+            vx_sweep_async(A, sk, sb + lo, len, T, p.top_k, a.iou_count, a.stamps ? a.stamps + b * VX_STAMP_WORDS + 8 : nullptr);
+            vx_async_emit(A, kg + lo, kd, &s_count2, kc);
+        }
+    }
+    __syncthreads();
+    VX_STAMP(5);
+    if (s_nexp > 0) {                                // vx_k_bm_finish completes this image
+        if (threadIdx.x == 0) {
+            a.bm.pend[2 * b] = nseg; a.bm.pend[2 * b + 1] = s_nexp;
+            vx_status_or(a.status, s_rbits);
+        }
+        return;
+    }
+    vx_image_tail(a, b, n, nseg, merge, sk, s_gcnt, &s_count2, s_rbits);
+#undef VX_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitmask path, last step on the image route: one workgroup per image that vx_k_nms_image left pending.  Every exported
+// segment is resolved from its edge list (vx_bm_scan; the chain sweep when the list overflowed), its kept keys go, in
+// order, to the segment's place in keys2 and their number to segk -- exactly what the sweeps of vx_k_nms_image leave --
+// and the image is finished by that kernel's tail.
+__global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    __shared__ union { vx_async_smem as; vx_bm_scan_smem sc; } U;
+    __shared__ int s_gcnt[VX_SORT_CHMAX / 64];
+    __shared__ int s_count2;
+    const vx_nms_params &p = a.p;
+    const int b = blockIdx.x;
+    const int nseg = a.bm.pend[2 * b], nexp = a.bm.pend[2 * b + 1];
+    if (nexp <= 0) return;
+    const int n = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    const long long ob = (long long)b * p.npad_cap;
+    const vx_thr T = vx_make_thr(p.thr);
+    int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
+    if (threadIdx.x == 0) s_count2 = 0;
+    for (int q = 0; q < nexp; ++q) {
+        const int si = a.bm.img_exp[b * VX_BM_MAXEXP + q];
+        const vx_bm_seg sg = a.bm.segs[si];
+        const long long region = ob + sg.lo;
+        const u64 *kseg = a.keys1 + region;
+        if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
+                       sg.len * VX_BM_ECAP, sg.len, p.top_k)) {
+            vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, a.keys2 + region, nullptr, segk + sg.id);
+        } else {
+            vx_sweep_async(U.as, sk, a.sbox + region, sg.len, T, p.top_k, a.iou_count);
+            vx_async_emit(U.as, kseg, a.keys2 + region, nullptr, segk + sg.id);
+        }
+    }
+    __syncthreads();
+    vx_image_tail(a, b, n, nseg, true, sk, s_gcnt, &s_count2, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2035,6 +2140,8 @@ struct vx_nms_ws {
     u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *segk; int *sel;
     int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
     int *part_runs;                                           // [B][VX_PART_MAX_CLASSES + 1] boundaries of the kept runs
+    vx_bm_ws bm;                                              // bitmask path (capacities beyond the single-launch kernel only)
+    int bm_on;
     size_t bytes;
 };
 
@@ -2057,6 +2164,26 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.part_segstart = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
     w.sel2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
     w.part_runs = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
+    // Bitmask path (vx_nms_bm.h).  Only capacities beyond the single-launch kernel carry it: below that the whole NMS
+    // is one launch and stays so.
+    w.bm = vx_bm_ws();
+    w.bm_on = npad_cap > VX_SORT_CHMAX;
+    if (w.bm_on) {
+        const int msi = vx_bm_max_segs_per_image(npad_cap);
+        w.bm.npad_cap = npad_cap;
+        w.bm.max_segs = B * msi;
+        w.bm.max_items = B * (npad_cap / 64 + msi);
+        w.bm.counters = (int *)(p + off); off += VX_BM_COUNTER_BYTES;
+        w.bm.segs = (vx_bm_seg *)(p + off); off += vx_align256n((size_t)w.bm.max_segs * sizeof(vx_bm_seg));
+        w.bm.ecount = (int *)(p + off); off += vx_align256n((size_t)w.bm.max_segs * sizeof(int));
+        w.bm.item_seg = (int *)(p + off); off += vx_align256n((size_t)w.bm.max_items * sizeof(int));
+        w.bm.tbb = (vx_f4 *)(p + off); off += vx_align256n((size_t)w.bm.max_items * sizeof(vx_f4));
+        w.bm.pend = (int *)(p + off); off += vx_align256n((size_t)B * 2 * sizeof(int));
+        w.bm.img_exp = (int *)(p + off); off += vx_align256n((size_t)B * VX_BM_MAXEXP * sizeof(int));
+        w.bm.recs = (vx_bm_rec *)(p + off); off += vx_align256n(n * sizeof(vx_bm_rec));
+        w.bm.edges = (unsigned *)(p + off); off += vx_align256n(n * VX_BM_ECAP * sizeof(unsigned));
+        w.bm.edges2 = (unsigned *)(p + off); off += vx_align256n(n * VX_BM_ECAP * sizeof(unsigned));
+    }
     w.bytes = off;
     return w;
 }
@@ -2120,6 +2247,9 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     // (sel[b] = their count, 0 = done) -- for an all-small batch its launches find nothing to do.
     const bool all_fit = npad_cap <= VX_SORT_CHMAX;
     const bool partitioned = n_classes >= VX_PART_MIN_CLASSES && n_classes <= VX_PART_MAX_CLASSES;
+    vx_image_args ia;
+    size_t ia_lds = 0;
+    int ia_threads = 1024;
     {
         static vx_attr_cache image_attr_set;
         if (vx_set_max_lds(image_attr_set, (const void *)vx_k_nms_image, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK)
@@ -2131,6 +2261,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg; a.segk = w.segk;   // phase clocks only while profiling
         a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only && !partitioned;
         a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
+        a.bm = w.bm; a.bm_on = w.bm_on;
+        if (w.bm_on && hipMemsetAsync(w.bm.counters, 0, VX_BM_COUNTER_BYTES, st) != hipSuccess) return VX_ERR_LAUNCH;
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
         int threads = lds_keys >= 1024 ? 1024 : 256;
         // the same LDS holds the sort keys and later the kept-box ring of the column-owner sweep
@@ -2146,7 +2278,30 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         vx_prof_begin(VX_PROF_NMS_IMAGE, st);
         hipLaunchKernelGGL(vx_k_nms_image, dim3(B), dim3(threads), lds, st, a);
         vx_prof_end(VX_PROF_NMS_IMAGE, st);
-        if (all_fit || (small_only && !partitioned)) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+        if (all_fit) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+        ia = a; ia_lds = lds; ia_threads = threads;
+    }
+    // bitmask path: pairs of every registered segment over the whole chip, then the per-image / per-segment scans
+    auto bm_launch = [&](const vx_part_args *part) -> int {
+        static vx_attr_cache finish_attr_set;
+        if (vx_set_max_lds(finish_attr_set, (const void *)vx_k_bm_finish, VX_SORT_CHMAX * (int)sizeof(u64)) != VX_OK) return VX_ERR_LAUNCH;
+        int wgs = (w.bm.max_items + 3) / 4;          // one wave per work item, at most the waves the chip holds (256 CUs x 8 WGs)
+        if (wgs > 4096) wgs = 4096;
+        vx_prof_begin(VX_PROF_BM_PAIRS, st);
+        hipLaunchKernelGGL(vx_k_bm_pairs, dim3(wgs), dim3(256), 0, st, w.bm, p.thr, vx_iou_counter());
+        vx_prof_end(VX_PROF_BM_PAIRS, st);
+        vx_prof_begin(VX_PROF_BM_SCAN, st);
+        hipLaunchKernelGGL(vx_k_bm_finish, dim3(B), dim3(ia_threads), ia_lds, st, ia);
+        if (part) {
+            int sg = w.bm.max_segs < 4096 ? w.bm.max_segs : 4096;
+            hipLaunchKernelGGL(vx_k_bm_scan, dim3(sg), dim3(256), vx_async_ring_bytes(4), st, *part);
+        }
+        vx_prof_end(VX_PROF_BM_SCAN, st);
+        return VX_OK;
+    };
+    if (small_only && !partitioned) {
+        if (bm_launch(nullptr) != VX_OK) return VX_ERR_LAUNCH;
+        return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
     d_counts = w.sel;                                  // from here on: only the images the kernel above left
 
@@ -2166,6 +2321,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.iou_count = vx_iou_counter();
         a.ordered = run_merge ? 1 : 0;
         a.defer = small_only; a.keep_counts = d_keep_counts;
+        a.bm = w.bm; a.bm_on = w.bm_on;
         pa = a;
         if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
             return VX_ERR_LAUNCH;
@@ -2181,6 +2337,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         vx_prof_end(VX_PROF_SWEEP, st);
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
     }
+    if (bm_launch(partitioned ? &pa : nullptr) != VX_OK) return VX_ERR_LAUNCH;
 
     // the general path (global sort, one workgroup per class for the sweep) takes the images left over; the optimistic
     // call with declared classes has deferred them instead (vx_k_part_scatter) and skips these launches
@@ -2364,4 +2521,12 @@ extern "C" size_t vx_batched_nms_stamps_offset(int B, int capacity) {
     if (B <= 0 || capacity <= 0 || capacity > VX_MAX_CANDIDATES) return 0;
     vx_nms_ws w = vx_nms_carve(nullptr, B, vx_next_pow2(capacity));
     return (size_t)((char *)w.stamps - (char *)nullptr);
+}
+
+// diagnostics: byte offset of the bitmask path's counter block (int[64]; [0] segments, [1] work items, [8..13] debug
+// counters of a -DVX_BM_DEBUG build) inside the NMS workspace, 0 when the capacity has no bitmask path
+extern "C" size_t vx_batched_nms_bm_counters_offset(int B, int capacity) {
+    if (B <= 0 || capacity <= 0 || capacity > VX_MAX_CANDIDATES) return 0;
+    vx_nms_ws w = vx_nms_carve(nullptr, B, vx_next_pow2(capacity));
+    return w.bm_on ? (size_t)((char *)w.bm.counters - (char *)nullptr) : 0;
 }

@@ -1,0 +1,502 @@
+// Whole-chip NMS of large class segments ("bitmask path"): the IoU tests of a segment no longer run on the one CU
+// that owns its greedy chain.  Three steps, each its own launch for all large segments of all images of a call:
+//
+//   prep   (inside the kernel that sorted the segment: vx_k_nms_image / vx_k_part_sweep)
+//          the segment's class-offset boxes, already in score order, are ALSO laid out by position: counting sort by
+//          the Morton code of the centre cell (32 x 32 cells over the segment's extent) into 32-byte records
+//          {box, area, score rank}; 64 consecutive records form a spatial tile with a bounding box.  The segment is
+//          registered in a device-side list, one work item per spatial tile.
+//   pairs  vx_k_bm_pairs, a grid over ALL work items (segment, tile B): one wave holds tile B's 64 boxes in its
+//          lanes and visits the tiles A it owns a pair with (every unordered tile pair has one owner, chosen so
+//          that each tile owns about half of its pairs) whose bounding boxes meet; of tile A only the boxes that
+//          reach into B's bounding box are tested (four per trip, the cheap candidate test of the chain sweep, the
+//          exact predicate for lanes that fail it).  The reference's predicate is symmetric in the two boxes, so a
+//          hit is stored once, as the edge (lower rank -> higher rank): "if the first box is kept, the second is
+//          suppressed".  Edges are staged per wave in LDS and appended to the segment's edge list.
+//   scan   (vx_k_bm_finish per image / vx_k_bm_scan per partitioned segment) the edges are counting-sorted by the
+//          score tile of their suppressor; one wave then walks the score tiles in order: alive = not yet suppressed,
+//          the tile's own edges resolve it greedily (bit walk over in-tile rows), the edges of its kept boxes
+//          mark later boxes dead.  No IoU arithmetic on this serial part.
+//
+// Exactness: a pair that is skipped has an empty intersection (one box lies outside the bounding box of the
+// other's tile), for which the reference's predicate is false whenever iou_threshold >= 0; every other pair is
+// decided by the same routines as the sweeps (vx_async_cand / vx_iou_gt).  Greedy NMS only needs, for every box, the
+// set of higher-ranked boxes that suppress it if kept: exactly the edge list.  Needs every box of the segment tame
+// (vx_tame) and a threshold inside the bracket's range (vx_thr::fast); a segment that does not qualify, or whose edges
+// outgrow its edge buffer (VX_BM_ECAP per box: heavily duplicated boxes), is swept by the chain sweep instead.
+//
+// Reference semantics: networks/modules/postprocess/utils/nms.py:57-98 (batched_nms), :105-123.
+#pragma once
+
+#define VX_BM_MIN 256                 // segments with more boxes than this take the bitmask path (<= 256: vx_sweep_wave)
+#define VX_BM_MAXN VX_SORT_CHMAX      // ... up to this many (ranks are 16-bit halves of an edge word; LDS tables of 256 tiles)
+#define VX_BM_ECAP 8                  // edge capacity per box of a segment
+#define VX_BM_GRID 32                 // cells per axis of the spatial sort (smallest boxes; 16 and 8 for the two larger size classes)
+#define VX_BM_CELLS (VX_BM_GRID * VX_BM_GRID + VX_BM_GRID * VX_BM_GRID / 4 + VX_BM_GRID * VX_BM_GRID / 16)   // 1344 = 64 * 21
+#define VX_BM_COUNTER_BYTES 256       // counter block: [0] segments, [1] work items, [8..13] debug
+#define VX_BM_STAGE 512               // edges staged per wave before a flush
+#define VX_BM_MAXEXP VX_SWEEP_MAXBIG  // exported segments per image on the single-launch route
+#define VX_BM_TRIP 4
+
+struct __attribute__((aligned(32))) vx_bm_rec { float x1, y1, x2, y2, area; int rank; int pad0, pad1; };
+struct __attribute__((aligned(32))) vx_bm_seg {
+    int b, lo, len, id;               // image, offset of the segment in the image's sorted arrays, boxes, segment index / class
+    int item_base, nt, route, pad;    // first work item (= index of tile 0's bounding box), tiles, 0 = image route / 1 = partitioned route
+};
+
+struct vx_bm_ws {
+    vx_bm_seg *segs;                  // [max_segs]
+    int *counters;                    // [0] segments registered, [1] work items reserved  (zeroed per call)
+    int *item_seg;                    // [max_items] work item -> segment
+    vx_f4 *tbb;                       // [max_items] bounding boxes of the spatial tiles
+    vx_bm_rec *recs;                  // [B * npad_cap] records in spatial order (a segment's records at its own offset)
+    unsigned *edges, *edges2;         // [B * npad_cap * VX_BM_ECAP] edge lists: as found / sorted by suppressor tile
+    int *ecount;                      // [max_segs] edges found (may exceed the capacity: overflow)
+    int *pend;                        // [B][2] image route: segment count and exported-segment count of an image the finish kernel completes
+    int *img_exp;                     // [B][VX_BM_MAXEXP] their descriptors
+    int npad_cap, max_segs, max_items;
+};
+
+__host__ __device__ __forceinline__ int vx_bm_max_segs_per_image(int cap) { return cap / (VX_BM_MIN + 1) + 1; }
+
+// ------------------------------------------------------------------------------------------------ prep
+struct vx_bm_prep_smem {
+    int hist[VX_BM_CELLS];
+    int ext[4];
+    int untame, fail, si, ib;
+};
+
+__device__ __forceinline__ unsigned vx_morton5(unsigned x, unsigned y) {       // 5 + 5 bits interleaved
+    x = (x | (x << 4)) & 0x10Fu; x = (x | (x << 2)) & 0x133u; x = (x | (x << 1)) & 0x155u;
+    y = (y | (y << 4)) & 0x10Fu; y = (y | (y << 2)) & 0x133u; y = (y | (y << 1)) & 0x155u;
+    return x | (y << 1);
+}
+
+// Whole workgroup.  sbox = the segment's class-offset boxes in score order (global, written by this workgroup before a
+// barrier).  Returns false (nothing registered) when a box is not tame.  region = b * npad_cap + lo.
+__device__ __noinline__ bool vx_bm_prep(vx_bm_prep_smem &S, const vx_bm_ws w, int b, int lo, int id, int route,
+                                        const vx_f4 *__restrict__ sbox, int n) {
+    const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6, nt = blockDim.x;
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int NT = (n + 63) >> 6;
+    const long long region = (long long)b * w.npad_cap + lo;
+    __syncthreads();
+    for (int i = threadIdx.x; i < VX_BM_CELLS; i += nt) S.hist[i] = 0;
+    if (threadIdx.x == 0) {
+        S.ext[0] = S.ext[1] = 0x7fffffff; S.ext[2] = S.ext[3] = (int)0x80000000;
+        S.untame = 0; S.fail = 0;
+    }
+    __syncthreads();
+    {
+        float mnx = 3e38f, mny = 3e38f, mxx = -3e38f, mxy = -3e38f;
+        bool bad = false;
+        for (int i = threadIdx.x; i < n; i += nt) {
+            const vx_f4 q = sbox[i];
+            bad |= !vx_tame(q, (q.z - q.x) * (q.w - q.y));
+            const float cx = q.x + q.z, cy = q.y + q.w;
+            mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx); mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, d)); mny = fminf(mny, __shfl_xor(mny, d));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, d)); mxy = fmaxf(mxy, __shfl_xor(mxy, d));
+        }
+        if (lane == 0) {
+            atomicMin(&S.ext[0], vx_f2ord(mnx)); atomicMin(&S.ext[1], vx_f2ord(mny));
+            atomicMax(&S.ext[2], vx_f2ord(mxx)); atomicMax(&S.ext[3], vx_f2ord(mxy));
+        }
+        if (__ballot(bad) != 0ull && lane == 0) S.untame = 1;
+    }
+    __syncthreads();
+    if (S.untame) { __syncthreads(); return false; }
+    if (threadIdx.x == 0) {
+        const int si = atomicAdd(&w.counters[0], 1), ib = atomicAdd(&w.counters[1], NT);
+        S.si = si; S.ib = ib;
+        if (si < w.max_segs && ib + NT <= w.max_items) {
+            vx_bm_seg sg;
+            sg.b = b; sg.lo = lo; sg.len = n; sg.id = id; sg.item_base = ib; sg.nt = NT; sg.route = route; sg.pad = 0;
+            w.segs[si] = sg;
+            w.ecount[si] = 0;
+        } else {
+            S.fail = 1;                                // cannot happen with the sizes of vx_bm_carve; never write out of bounds
+        }
+    }
+    // Cells: the boxes are split into three size classes (larger side below 1/8, below 1/4, from 1/4 of the extent of
+    // the centres), each with its own grid (32 x 32, 16 x 16, 8 x 8 cells, Morton order inside), smallest class first:
+    // a tile then holds boxes of one size and its bounding box stays close to the cells it covers -- a single large
+    // box in a tile of small ones would make the tile meet half the segment.  (Any assignment of boxes to cells is
+    // correct: the cells only decide which boxes share a tile.)
+    const float ex0 = vx_ord2f(S.ext[0]), ey0 = vx_ord2f(S.ext[1]);
+    const float exw = fmaxf(vx_ord2f(S.ext[2]) - ex0, 1e-30f), eyw = fmaxf(vx_ord2f(S.ext[3]) - ey0, 1e-30f);   // 2 x the extent
+    const float sx = 1.0f / exw, sy = 1.0f / eyw;
+    const float s1 = 0.5f * fmaxf(exw, eyw) * 0.125f, s2 = 2.0f * s1;
+    auto cell_of = [&](const vx_f4 &q) __attribute__((always_inline)) -> int {
+        const float sz = fmaxf(q.z - q.x, q.w - q.y);
+        const int level = sz < s1 ? 0 : (sz < s2 ? 1 : 2);
+        const int g = VX_BM_GRID >> level;
+        const int base = level == 0 ? 0 : (level == 1 ? VX_BM_GRID * VX_BM_GRID : VX_BM_GRID * VX_BM_GRID + VX_BM_GRID * VX_BM_GRID / 4);
+        const int cx = min(g - 1, max(0, (int)((q.x + q.z - ex0) * sx * (float)g)));
+        const int cy = min(g - 1, max(0, (int)((q.y + q.w - ey0) * sy * (float)g)));
+        return base + (int)vx_morton5((unsigned)cx, (unsigned)cy);
+    };
+    for (int i = threadIdx.x; i < n; i += nt) atomicAdd(&S.hist[cell_of(sbox[i])], 1);
+    __syncthreads();
+    if (S.fail) { __syncthreads(); return false; }
+    if (wv == 0) {                                      // exclusive scan of the cell counts: 21 per lane
+        constexpr int PER = VX_BM_CELLS / 64;
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) tot += S.hist[lane * PER + q];
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { const int v = S.hist[lane * PER + q]; S.hist[lane * PER + q] = run; run += v; }
+    }
+    __syncthreads();
+    vx_bm_rec *recs = w.recs + region;
+    for (int i = threadIdx.x; i < n; i += nt) {         // scatter into cell order (any order inside a cell)
+        const vx_f4 q = sbox[i];
+        const int pos = atomicAdd(&S.hist[cell_of(q)], 1);
+        vx_bm_rec r;
+        r.x1 = q.x; r.y1 = q.y; r.x2 = q.z; r.y2 = q.w; r.area = (q.z - q.x) * (q.w - q.y); r.rank = i; r.pad0 = 0; r.pad1 = 0;
+        recs[pos] = r;
+    }
+    __syncthreads();                                    // the records are visible to this workgroup
+    const int ib = S.ib, si = S.si;
+    for (int v = wv; v < NT; v += W) {                  // bounding boxes of the spatial tiles
+        vx_f4 q = {3e38f, 3e38f, -3e38f, -3e38f};
+        if (v * 64 + lane < n) {
+            const vx_bm_rec r = recs[v * 64 + lane];
+            q.x = r.x1; q.y = r.y1; q.z = r.x2; q.w = r.y2;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            q.x = fminf(q.x, __shfl_xor(q.x, d)); q.y = fminf(q.y, __shfl_xor(q.y, d));
+            q.z = fmaxf(q.z, __shfl_xor(q.z, d)); q.w = fmaxf(q.w, __shfl_xor(q.w, d));
+        }
+        if (lane == 0) { w.tbb[ib + v] = q; w.item_seg[ib + v] = si; }
+    }
+    __syncthreads();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ pairs
+// The candidate test of the chain sweep, keeping its intermediate values: for two tame boxes c = inter1 - lo * uni1 < 0
+// (height left unclamped) proves the reference's predicate false; where c >= 0 both extents are positive, so inter1 and
+// uni1 ARE the reference's inter and uni and the bracket / division finish the decision without recomputing them.
+__device__ __forceinline__ float vx_bm_cand(const vx_f4 &K, float ka, const vx_f4 &bx, float a, float lo, float &inter, float &uni) {
+    const float xx1 = vx_vmax<false>(K.x, bx.x);
+    const float yy1 = vx_vmax<false>(K.y, bx.y);
+    const float xx2 = vx_vmin<false>(K.z, bx.z);
+    const float yy2 = vx_vmin<false>(K.w, bx.w);
+    const float w = vx_vmax<false>(xx2 - xx1, 0.0f);
+    inter = w * (yy2 - yy1);
+    uni = ka + a - inter;
+    return inter - lo * uni;
+}
+
+#define VX_BM_STAGE_PAIRS 256          // edges staged per wave of vx_k_bm_pairs before a flush
+
+__global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr_, unsigned long long *iou_count) {
+    __shared__ unsigned s_e[4][VX_BM_STAGE_PAIRS];
+    struct __attribute__((aligned(32))) lrec { vx_f4 b; vx_f2 ar; vx_f2 pad; };
+    __shared__ lrec s_rec[4][64];                        // the visited tile A: box, (area, score rank) -- one address per box
+    const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nitems = min(w.counters[1], w.max_items);
+    const vx_thr T = vx_make_thr(thr_);
+    unsigned *se = s_e[wv];
+    lrec *srec = s_rec[wv];
+    unsigned long long tests = 0ull;
+#ifdef VX_BM_DEBUG
+    int d_items = 0, d_visits = 0, d_trips = 0, d_hitq = 0, d_edges = 0, d_tilepairs = 0;
+#define VX_BM_DBG(x) x
+#else
+#define VX_BM_DBG(x)
+#endif
+    // Static deal of the work items, one wave each per round.  (A/B on MI355X: a device-side work queue -- eight
+    // atomic heads, a look before each atomic -- balanced the tail but took 0.56 ms instead of 0.33 ms on the FPN-SSD
+    // batch (27 000 short items) and 0.23 instead of 0.21 ms on RetinaFace: the returning atomics cost more than
+    // the imbalance.)
+    for (int it = blockIdx.x * 4 + wv; it < nitems; it += gridDim.x * 4) {
+        // wave-uniform values are made so explicitly (readfirstlane): loads land in vector registers and everything
+        // derived from them would be treated as divergent
+        const int si = __builtin_amdgcn_readfirstlane(w.item_seg[it]);
+        if (si < 0 || si >= w.max_segs) continue;
+        const vx_bm_seg *sgp = w.segs + si;
+        const int item_base = __builtin_amdgcn_readfirstlane(sgp->item_base);
+        const int Bt = it - item_base, n = __builtin_amdgcn_readfirstlane(sgp->len), NT = __builtin_amdgcn_readfirstlane(sgp->nt);
+        const long long region = (long long)__builtin_amdgcn_readfirstlane(sgp->b) * w.npad_cap + __builtin_amdgcn_readfirstlane(sgp->lo);
+        const vx_bm_rec *__restrict__ recs = w.recs + region;
+        const vx_f4 *__restrict__ tbb = w.tbb + item_base;
+        unsigned *eout = w.edges + region * VX_BM_ECAP;
+        const int ecap = n * VX_BM_ECAP;
+        int *ecnt = w.ecount + si;
+        struct rec6 { vx_f4 b; float area; int rank; };
+        auto load_tile = [&](int A) __attribute__((always_inline)) -> rec6 {
+            rec6 r;
+            r.b.x = r.b.y = r.b.z = r.b.w = 1e30f; r.area = 0.0f; r.rank = 0;       // a box that meets nothing
+            if (A >= 0 && A * 64 + lane < n) {
+                const vx_bm_rec *g = recs + A * 64 + lane;
+                r.b = *reinterpret_cast<const vx_f4 *>(g);
+                const vx_f2 t = *reinterpret_cast<const vx_f2 *>(&g->area);
+                r.area = t.x; r.rank = __float_as_int(t.y);
+            }
+            return r;
+        };
+        // this lane's box (tile B)
+        const rec6 me = load_tile(Bt);
+        const vx_f4 bx = me.b;
+        const float ar = me.area;
+        const int rk = me.rank;
+        const u64 vmask = vx_uniform64(__ballot(Bt * 64 + lane < n));
+        const vx_f4 bb = tbb[Bt];
+        int cnt = 0;                                    // staged edges (wave-uniform)
+        auto flush = [&]() __attribute__((always_inline)) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(ecnt, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            for (int k = lane; k < cnt; k += 64)
+                if (base + k < ecap) eout[base + k] = se[k];
+            cnt = 0;
+        };
+        // tiles A this item owns a pair with and whose bounding boxes meet B's (lane = tile; NT <= 256: four masks).
+        // Every unordered tile pair has ONE owner, the tile whose boxes sit in the lanes: the one with the smaller
+        // bounding box (the boxes of the wide tile are then culled against a small target; the other way round nearly
+        // every box of the small tile reaches into the wide one) -- equal areas: by index parity, about half each.
+        const float bb_area = (bb.z - bb.x) * (bb.w - bb.y);
+        u64 tmq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int Al = c * 64 + lane;
+            bool meet = false;
+            if (Al < NT) {
+                const vx_f4 ta = tbb[Al];
+                const float ta_area = (ta.z - ta.x) * (ta.w - ta.y);
+                const bool par = (Al < Bt) == (((Al + Bt) & 1) != 0);
+                const bool owned = Al == Bt || bb_area < ta_area || (bb_area == ta_area && par);
+                meet = owned && !(ta.z <= bb.x || ta.x >= bb.z || ta.w <= bb.y || ta.y >= bb.w);
+            }
+            tmq[c] = c * 64 < NT ? vx_uniform64(__ballot(meet)) : 0ull;
+        }
+        auto next_tile = [&]() __attribute__((always_inline)) -> int {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (tmq[c]) { const int A = c * 64 + __builtin_ctzll(tmq[c]); tmq[c] &= tmq[c] - 1ull; return A; }
+            return -1;
+        };
+        int A = __builtin_amdgcn_readfirstlane(next_tile());
+        rec6 rc = load_tile(A);
+        VX_BM_DBG(++d_items;)
+        while (A >= 0) {
+            VX_BM_DBG(++d_tilepairs;)
+            const int An = __builtin_amdgcn_readfirstlane(next_tile());
+            const rec6 rn = load_tile(An);              // in flight during this visit
+            const bool diag = A == Bt;
+            // boxes of tile A that reach into B's bounding box (lane = box of A; the filler box of a short tile reaches nothing)
+            u64 m = vx_uniform64(__ballot(!(rc.b.z <= bb.x || rc.b.x >= bb.z || rc.b.w <= bb.y || rc.b.y >= bb.w)));
+            if (diag && !(m & (m - 1ull))) m = 0ull;     // a single box has no partner in its own tile
+            if (m) {
+                VX_BM_DBG(++d_visits;)
+                srec[lane].b = rc.b;
+                vx_f2 t; t.x = rc.area; t.y = __int_as_float(rc.rank);
+                srec[lane].ar = t;
+                __builtin_amdgcn_wave_barrier();
+                while (m) {
+                    int ki[VX_BM_TRIP];
+                    int last = 0;
+#pragma unroll
+                    for (int q = 0; q < VX_BM_TRIP; ++q) {
+                        if (m) { last = __builtin_ctzll(m); m &= m - 1ull; }
+                        ki[q] = last;                   // a short last trip repeats its last box
+                    }
+                    vx_f4 K[VX_BM_TRIP];
+                    float ka[VX_BM_TRIP];
+                    int kr[VX_BM_TRIP];
+#pragma unroll
+                    for (int q = 0; q < VX_BM_TRIP; ++q) {
+                        K[q] = srec[ki[q]].b;
+                        const vx_f2 t2 = srec[ki[q]].ar;
+                        ka[q] = t2.x; kr[q] = __float_as_int(t2.y);
+                    }
+                    tests += (unsigned long long)VX_BM_TRIP * __popcll(vmask);
+                    VX_BM_DBG(++d_trips;)
+                    u64 hitq[VX_BM_TRIP];
+                    float in_[VX_BM_TRIP], un_[VX_BM_TRIP];
+#pragma unroll
+                    for (int q = 0; q < VX_BM_TRIP; ++q) {
+                        const float c = vx_bm_cand(K[q], ka[q], bx, ar, T.lo, in_[q], un_[q]);
+                        hitq[q] = vx_uniform64(__ballot(!(c < 0.0f)) & vmask);
+                    }
+#pragma unroll
+                    for (int q = 0; q < VX_BM_TRIP; ++q) {
+                        u64 part = hitq[q];
+                        if (q > 0 && ki[q] == ki[q - 1]) part = 0ull;           // the repeated box of a short last trip
+                        if (diag) part &= ~((2ull << ki[q]) - 1ull);            // own tile: later lanes only
+                        if (!part) continue;
+                        VX_BM_DBG(++d_hitq;)
+                        // exact decision for the candidate lanes: bracket (inter > hi * uni), the IEEE division where
+                        // the bracket cannot decide (the candidate test already excluded inter < lo * uni)
+                        const bool mine = (part >> lane) & 1ull;
+                        bool sup_l = in_[q] > T.hi * un_[q];
+                        const u64 und = vx_uniform64(__ballot(mine && !sup_l));
+                        if (und) sup_l = sup_l || (in_[q] / un_[q]) > T.thr;
+                        const u64 sup = vx_uniform64(__ballot(sup_l) & part);
+                        if (sup) {
+                            if ((sup >> lane) & 1ull) {
+                                const unsigned a_ = (unsigned)min(rk, kr[q]), b_ = (unsigned)max(rk, kr[q]);
+                                se[cnt + vx_mbcnt(sup)] = (a_ << 16) | b_;
+                            }
+                            cnt = __builtin_amdgcn_readfirstlane(cnt + __popcll(sup));
+                            VX_BM_DBG(d_edges += __popcll(sup);)
+                            if (cnt > VX_BM_STAGE_PAIRS - 64) flush();
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            A = An;
+            rc = rn;
+        }
+        if (cnt) flush();
+    }
+    if (iou_count && tests && lane == 0) atomicAdd(iou_count, tests);
+#ifdef VX_BM_DEBUG
+    if (lane == 0) {
+        atomicAdd(&w.counters[8], d_items); atomicAdd(&w.counters[9], d_tilepairs); atomicAdd(&w.counters[10], d_visits);
+        atomicAdd(&w.counters[11], d_trips); atomicAdd(&w.counters[12], d_hitq); atomicAdd(&w.counters[13], d_edges);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+struct vx_bm_scan_smem {
+    int start[VX_BM_MAXN / 64 + 1];
+    int cur[VX_BM_MAXN / 64];
+    u64 dead[VX_BM_MAXN / 64];
+    u64 kept[VX_BM_MAXN / 64];       // the result: kept masks of the score tiles [0, ndone)
+    u64 rows[64];
+    int ndone;
+};
+
+// Whole workgroup.  edges[0..ecount) of a segment of n boxes -> kept masks in S.kept[0..S.ndone) (cut to the first top_k
+// kept boxes when top_k > 0).  Returns false (nothing done) when the edge list overflowed.  Ends synchronised.
+__device__ __noinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *__restrict__ edges2,
+                                        int ecount, int ecap, int n, int top_k) {
+    const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nt = blockDim.x;
+    n = __builtin_amdgcn_readfirstlane(n);
+    ecount = __builtin_amdgcn_readfirstlane(ecount);
+    if (ecount > ecap) return false;
+    const int NT = (n + 63) >> 6, E = ecount;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT; i += nt) { S.cur[i] = 0; S.dead[i] = 0ull; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < E; k += nt) atomicAdd(&S.cur[edges[k] >> 22], 1);      // (lo rank >> 6) = bits 22..
+    __syncthreads();
+    if (wv == 0) {                                      // exclusive scan of <= 256 counters: 4 per lane
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int t = lane * 4 + q; v[q] = t < NT ? S.cur[t] : 0; tot += v[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = lane * 4 + q;
+            if (t < NT) { S.start[t] = run; S.cur[t] = run; }
+            run += v[q];
+        }
+        if (lane == 63) S.start[NT] = incl;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < E; k += nt) {
+        const unsigned e = edges[k];
+        edges2[atomicAdd(&S.cur[e >> 22], 1)] = e;
+    }
+    __syncthreads();                                    // edges2 is visible to this workgroup
+    if (wv == 0) {
+        // The tile's edges live in registers (4 per lane; a tile with more than 256 edges reads the rest from memory)
+        // and the next tile's are requested before this tile is resolved: the chain never waits for a cold load.
+        constexpr unsigned NONE = 0xFFFFFFFFu;         // lo = hi = 65535: matches no tile
+        auto load4 = [&](int t, unsigned *e) __attribute__((always_inline)) {
+            const int s0 = t < NT ? S.start[t] : 0, s1 = t < NT ? S.start[t + 1] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k = s0 + q * 64 + lane; e[q] = k < s1 ? edges2[k] : NONE; }
+        };
+        unsigned ec[4], en[4];
+        load4(0, ec);
+        int ktot = 0, ndone = NT;
+        for (int t = 0; t < NT; ++t) {
+            load4(t + 1, en);
+            const int s0 = S.start[t], s1 = S.start[t + 1];
+            const int rem = n - t * 64;
+            u64 alive = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & ~S.dead[t];
+            alive = vx_uniform64(alive);
+            if (s1 > s0 && alive) {
+                // the tile's own edges -> in-tile rows, resolved greedily by a bit walk over the boxes that suppress somebody
+                S.rows[lane] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
+                    if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
+                }
+                for (int k = s0 + 256 + lane; k < s1; k += 64) {
+                    const unsigned e = edges2[k];
+                    const unsigned lo = e >> 16, hi = e & 0xFFFFu;
+                    if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
+                }
+                if (__ballot(any)) {
+                    __builtin_amdgcn_wave_barrier();
+                    const u64 row = S.rows[lane];
+                    const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
+                    const u64 has = __ballot(row != 0ull);
+                    u64 todo = alive & has;
+                    while (todo) {
+                        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                        const u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                                       (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
+                        alive &= ~mi;
+                        todo = alive & has & ~((2ull << i) - 1ull);
+                    }
+                }
+            }
+            int nk = __popcll(alive);
+            bool stop = false;
+            if (top_k > 0 && ktot + nk >= top_k) {       // only the segment's first top_k kept boxes matter
+                int excess = ktot + nk - top_k;
+                while (excess-- > 0) alive &= ~(1ull << (63 - __builtin_clzll(alive)));
+                nk = top_k - ktot;
+                stop = true;
+            }
+            ktot += nk;
+            if (lane == 0) S.kept[t] = alive;
+            if (stop) { ndone = t + 1; break; }
+            if (alive && s1 > s0) {                      // edges of the kept boxes: their targets in later tiles die
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
+                    if (ec[q] != NONE && ((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
+                        atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
+                }
+                for (int k = s0 + 256 + lane; k < s1; k += 64) {
+                    const unsigned e = edges2[k];
+                    const unsigned lo = e >> 16, hi = e & 0xFFFFu;
+                    if (((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
+                        atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ec[q] = en[q];
+        }
+        if (lane == 0) S.ndone = ndone;
+    }
+    __syncthreads();
+    return true;
+}

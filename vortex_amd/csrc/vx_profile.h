@@ -6,7 +6,7 @@
 enum vx_prof_slot {
     VX_PROF_PREPROCESS = 0, VX_PROF_HEAD_DECODE, VX_PROF_DECODE_ROWS, VX_PROF_FUSED, VX_PROF_FINISH,
     VX_PROF_PRIOR, VX_PROF_NMS_KEYS, VX_PROF_SORT1, VX_PROF_SWEEP, VX_PROF_SORT2, VX_PROF_PACK, VX_PROF_NMS_IMAGE,
-    VX_PROF_DETR, VX_PROF_SOFTMAX,
+    VX_PROF_DETR, VX_PROF_SOFTMAX, VX_PROF_BM_PAIRS, VX_PROF_BM_SCAN,
     VX_PROF_NSLOTS
 };
 
