@@ -200,18 +200,83 @@ __device__ __forceinline__ float vx_bm_cand(const vx_f4 &K, float ka, const vx_f
 
 #define VX_BM_STAGE_PAIRS 256          // edges staged per wave of vx_k_bm_pairs before a flush
 
+// LDS copy of the boxes of the visited tile A that reach into B's bounding box, compacted (a trip reads four
+// consecutive records: one address, immediate offsets; no per-box bit extraction on the scalar unit, which is what
+// bounds this kernel) and padded with three records that meet nothing.
+struct __attribute__((aligned(32))) vx_bm_lrec { vx_f4 b; float area; int rank; int lane; int pad; };
+
+struct vx_bm_wave_ctx {                // per-wave state of vx_k_bm_pairs (all wave-uniform except the lane's box)
+    vx_bm_lrec *srec;                  // [64 + 4]
+    unsigned *se;                      // [VX_BM_STAGE_PAIRS] staged edges
+    unsigned *eout;                    // the segment's edge list
+    int *ecnt;
+    int ecap, cnt;
+};
+
+__device__ __forceinline__ void vx_bm_flush(vx_bm_wave_ctx &C) {
+    const int lane = vx_lane();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(C.ecnt, C.cnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int k = lane; k < C.cnt; k += 64)
+        if (base + k < C.ecap) C.eout[base + k] = C.se[k];
+    C.cnt = 0;
+}
+
+// All trips of one visit: nreach compacted records of tile A against this lane's box (tile B).  DIAG: A is the lane's own
+// tile; a record only pairs with later lanes.
+template <bool DIAG>
+__device__ __forceinline__ void vx_bm_visit(vx_bm_wave_ctx &C, int nreach, const vx_f4 &bx, float ar, int rk, u64 vmask, const vx_thr &T) {
+    const int lane = vx_lane();
+    for (int j = 0; j < nreach; j += VX_BM_TRIP) {
+        vx_bm_lrec K[VX_BM_TRIP];
+#pragma unroll
+        for (int q = 0; q < VX_BM_TRIP; ++q) K[q] = C.srec[j + q];
+        u64 hit[VX_BM_TRIP], any = 0ull;
+        float in_[VX_BM_TRIP], un_[VX_BM_TRIP];
+#pragma unroll
+        for (int q = 0; q < VX_BM_TRIP; ++q) {
+            float c = vx_bm_cand(K[q].b, K[q].area, bx, ar, T.lo, in_[q], un_[q]);
+            if (DIAG) c = lane > K[q].lane ? c : -1.0f;
+            hit[q] = vx_uniform64(__ballot(!(c < 0.0f)) & vmask);
+            any |= hit[q];
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int q = 0; q < VX_BM_TRIP; ++q) {
+            const u64 part = hit[q];
+            if (!part) continue;
+            // exact decision for the candidate lanes: bracket (inter > hi * uni), the IEEE division where the bracket
+            // cannot decide (the candidate test already excluded inter < lo * uni)
+            const bool mine = (part >> lane) & 1ull;
+            bool sup_l = in_[q] > T.hi * un_[q];
+            const u64 und = vx_uniform64(__ballot(mine && !sup_l));
+            if (und) sup_l = sup_l || (in_[q] / un_[q]) > T.thr;
+            const u64 sup = vx_uniform64(__ballot(sup_l) & part);
+            if (sup) {
+                if ((sup >> lane) & 1ull) {
+                    const unsigned a_ = (unsigned)min(rk, K[q].rank), b_ = (unsigned)max(rk, K[q].rank);
+                    C.se[C.cnt + vx_mbcnt(sup)] = (a_ << 16) | b_;
+                }
+                C.cnt = __builtin_amdgcn_readfirstlane(C.cnt + __popcll(sup));
+                if (C.cnt > VX_BM_STAGE_PAIRS - 64) vx_bm_flush(C);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr_, unsigned long long *iou_count) {
     __shared__ unsigned s_e[4][VX_BM_STAGE_PAIRS];
-    struct __attribute__((aligned(32))) lrec { vx_f4 b; vx_f2 ar; vx_f2 pad; };
-    __shared__ lrec s_rec[4][64];                        // the visited tile A: box, (area, score rank) -- one address per box
+    __shared__ vx_bm_lrec s_rec[4][64 + 4];
     const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nitems = min(w.counters[1], w.max_items);
     const vx_thr T = vx_make_thr(thr_);
-    unsigned *se = s_e[wv];
-    lrec *srec = s_rec[wv];
+    vx_bm_wave_ctx C;
+    C.se = s_e[wv];
+    C.srec = s_rec[wv];
     unsigned long long tests = 0ull;
 #ifdef VX_BM_DEBUG
-    int d_items = 0, d_visits = 0, d_trips = 0, d_hitq = 0, d_edges = 0, d_tilepairs = 0;
+    int d_items = 0, d_visits = 0, d_trips = 0, d_tilepairs = 0;
 #define VX_BM_DBG(x) x
 #else
 #define VX_BM_DBG(x)
@@ -231,9 +296,10 @@ __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr
         const long long region = (long long)__builtin_amdgcn_readfirstlane(sgp->b) * w.npad_cap + __builtin_amdgcn_readfirstlane(sgp->lo);
         const vx_bm_rec *__restrict__ recs = w.recs + region;
         const vx_f4 *__restrict__ tbb = w.tbb + item_base;
-        unsigned *eout = w.edges + region * VX_BM_ECAP;
-        const int ecap = n * VX_BM_ECAP;
-        int *ecnt = w.ecount + si;
+        C.eout = w.edges + region * VX_BM_ECAP;
+        C.ecap = n * VX_BM_ECAP;
+        C.ecnt = w.ecount + si;
+        C.cnt = 0;
         struct rec6 { vx_f4 b; float area; int rank; };
         auto load_tile = [&](int A) __attribute__((always_inline)) -> rec6 {
             rec6 r;
@@ -252,20 +318,13 @@ __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr
         const float ar = me.area;
         const int rk = me.rank;
         const u64 vmask = vx_uniform64(__ballot(Bt * 64 + lane < n));
+        const int nvalid = __popcll(vmask);
         const vx_f4 bb = tbb[Bt];
-        int cnt = 0;                                    // staged edges (wave-uniform)
-        auto flush = [&]() __attribute__((always_inline)) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(ecnt, cnt);
-            base = __builtin_amdgcn_readfirstlane(base);
-            for (int k = lane; k < cnt; k += 64)
-                if (base + k < ecap) eout[base + k] = se[k];
-            cnt = 0;
-        };
         // tiles A this item owns a pair with and whose bounding boxes meet B's (lane = tile; NT <= 256: four masks).
         // Every unordered tile pair has ONE owner, the tile whose boxes sit in the lanes: the one with the smaller
         // bounding box (the boxes of the wide tile are then culled against a small target; the other way round nearly
         // every box of the small tile reaches into the wide one) -- equal areas: by index parity, about half each.
+        // A/B on MI355X (RetinaFace b128 / FPN-SSD b64, this kernel): parity only 0.47 / 0.47 ms, smaller box 0.21 / 0.33.
         const float bb_area = (bb.z - bb.x) * (bb.w - bb.y);
         u64 tmq[4];
 #pragma unroll
@@ -296,77 +355,37 @@ __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr
             const rec6 rn = load_tile(An);              // in flight during this visit
             const bool diag = A == Bt;
             // boxes of tile A that reach into B's bounding box (lane = box of A; the filler box of a short tile reaches nothing)
-            u64 m = vx_uniform64(__ballot(!(rc.b.z <= bb.x || rc.b.x >= bb.z || rc.b.w <= bb.y || rc.b.y >= bb.w)));
-            if (diag && !(m & (m - 1ull))) m = 0ull;     // a single box has no partner in its own tile
-            if (m) {
-                VX_BM_DBG(++d_visits;)
-                srec[lane].b = rc.b;
-                vx_f2 t; t.x = rc.area; t.y = __int_as_float(rc.rank);
-                srec[lane].ar = t;
-                __builtin_amdgcn_wave_barrier();
-                while (m) {
-                    int ki[VX_BM_TRIP];
-                    int last = 0;
-#pragma unroll
-                    for (int q = 0; q < VX_BM_TRIP; ++q) {
-                        if (m) { last = __builtin_ctzll(m); m &= m - 1ull; }
-                        ki[q] = last;                   // a short last trip repeats its last box
-                    }
-                    vx_f4 K[VX_BM_TRIP];
-                    float ka[VX_BM_TRIP];
-                    int kr[VX_BM_TRIP];
-#pragma unroll
-                    for (int q = 0; q < VX_BM_TRIP; ++q) {
-                        K[q] = srec[ki[q]].b;
-                        const vx_f2 t2 = srec[ki[q]].ar;
-                        ka[q] = t2.x; kr[q] = __float_as_int(t2.y);
-                    }
-                    tests += (unsigned long long)VX_BM_TRIP * __popcll(vmask);
-                    VX_BM_DBG(++d_trips;)
-                    u64 hitq[VX_BM_TRIP];
-                    float in_[VX_BM_TRIP], un_[VX_BM_TRIP];
-#pragma unroll
-                    for (int q = 0; q < VX_BM_TRIP; ++q) {
-                        const float c = vx_bm_cand(K[q], ka[q], bx, ar, T.lo, in_[q], un_[q]);
-                        hitq[q] = vx_uniform64(__ballot(!(c < 0.0f)) & vmask);
-                    }
-#pragma unroll
-                    for (int q = 0; q < VX_BM_TRIP; ++q) {
-                        u64 part = hitq[q];
-                        if (q > 0 && ki[q] == ki[q - 1]) part = 0ull;           // the repeated box of a short last trip
-                        if (diag) part &= ~((2ull << ki[q]) - 1ull);            // own tile: later lanes only
-                        if (!part) continue;
-                        VX_BM_DBG(++d_hitq;)
-                        // exact decision for the candidate lanes: bracket (inter > hi * uni), the IEEE division where
-                        // the bracket cannot decide (the candidate test already excluded inter < lo * uni)
-                        const bool mine = (part >> lane) & 1ull;
-                        bool sup_l = in_[q] > T.hi * un_[q];
-                        const u64 und = vx_uniform64(__ballot(mine && !sup_l));
-                        if (und) sup_l = sup_l || (in_[q] / un_[q]) > T.thr;
-                        const u64 sup = vx_uniform64(__ballot(sup_l) & part);
-                        if (sup) {
-                            if ((sup >> lane) & 1ull) {
-                                const unsigned a_ = (unsigned)min(rk, kr[q]), b_ = (unsigned)max(rk, kr[q]);
-                                se[cnt + vx_mbcnt(sup)] = (a_ << 16) | b_;
-                            }
-                            cnt = __builtin_amdgcn_readfirstlane(cnt + __popcll(sup));
-                            VX_BM_DBG(d_edges += __popcll(sup);)
-                            if (cnt > VX_BM_STAGE_PAIRS - 64) flush();
-                        }
-                    }
+            const bool reach = !(rc.b.z <= bb.x || rc.b.x >= bb.z || rc.b.w <= bb.y || rc.b.y >= bb.w);
+            const u64 m = vx_uniform64(__ballot(reach));
+            const int nreach = __popcll(m);
+            if (nreach > (diag ? 1 : 0)) {                // a single box has no partner in its own tile
+                VX_BM_DBG(++d_visits; d_trips += (nreach + 3) >> 2;)
+                if (reach) {
+                    vx_bm_lrec r;
+                    r.b = rc.b; r.area = rc.area; r.rank = rc.rank; r.lane = lane; r.pad = 0;
+                    C.srec[vx_mbcnt(m)] = r;
                 }
+                if (lane < VX_BM_TRIP - 1) {              // a short last trip reads records that meet nothing
+                    vx_bm_lrec r;
+                    r.b.x = r.b.y = r.b.z = r.b.w = 1e30f; r.area = 0.0f; r.rank = 0; r.lane = 64; r.pad = 0;
+                    C.srec[nreach + lane] = r;
+                }
+                __builtin_amdgcn_wave_barrier();
+                tests += (unsigned long long)nreach * nvalid;
+                if (diag) vx_bm_visit<true>(C, nreach, bx, ar, rk, vmask, T);
+                else vx_bm_visit<false>(C, nreach, bx, ar, rk, vmask, T);
                 __builtin_amdgcn_wave_barrier();
             }
             A = An;
             rc = rn;
         }
-        if (cnt) flush();
+        if (C.cnt) vx_bm_flush(C);
     }
     if (iou_count && tests && lane == 0) atomicAdd(iou_count, tests);
 #ifdef VX_BM_DEBUG
     if (lane == 0) {
         atomicAdd(&w.counters[8], d_items); atomicAdd(&w.counters[9], d_tilepairs); atomicAdd(&w.counters[10], d_visits);
-        atomicAdd(&w.counters[11], d_trips); atomicAdd(&w.counters[12], d_hitq); atomicAdd(&w.counters[13], d_edges);
+        atomicAdd(&w.counters[11], d_trips);
     }
 #endif
 }
