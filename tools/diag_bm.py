@@ -9,7 +9,7 @@ from oracle import vortex_oracle as O
 DEV = torch.device("cuda:0")
 
 
-def make(B, K, C, seed, n=None, wh=(0.02, 0.2), dup=0, untame=False):
+def make(B, K, C, seed, n=None, wh=(0.02, 0.2), dup=0, untame=False, ties=0):
     g = torch.Generator().manual_seed(seed)
     c = torch.rand(B, K, 2, generator=g)
     s = torch.rand(B, K, 2, generator=g) * (wh[1] - wh[0]) + wh[0]
@@ -19,6 +19,8 @@ def make(B, K, C, seed, n=None, wh=(0.02, 0.2), dup=0, untame=False):
     if untame:
         boxes[:, 5, 2] = boxes[:, 5, 0] - 0.1
     scores = torch.rand(B, K, generator=g)
+    if ties:
+        scores = (scores * ties).floor() / ties          # only `ties` distinct scores
     cls = torch.randint(0, C, (B, K), generator=g, dtype=torch.int64)
     det = torch.cat((boxes, scores[..., None], cls[..., None].float()), 2).contiguous()
     counts = None
@@ -32,6 +34,11 @@ def check(name, B, K, C, thr=0.45, top_k=None, optimistic=False, **kw):
     d = [t.to(DEV) if t is not None else None for t in (boxes, scores, cls, det, counts)]
     keep_idx, out_det, keep_counts, status = ops.batched_nms(d[0], d[1], d[2], d[3], d[4], thr, C, top_k, optimistic=optimistic)
     torch.cuda.synchronize()
+    redo = ""
+    if optimistic and (int(status.item()) & L.VX_STATUS_DEFERRED):      # the optimistic bet was lost: the full call
+        keep_idx, out_det, keep_counts, status = ops.batched_nms(d[0], d[1], d[2], d[3], d[4], thr, C, top_k)
+        torch.cuda.synchronize()
+        redo = " (deferred -> redone)"
     kc = keep_counts.cpu().tolist()
     ok = True
     for b in range(B):
@@ -52,7 +59,7 @@ def check(name, B, K, C, thr=0.45, top_k=None, optimistic=False, **kw):
     for _ in range(5):
         ops.batched_nms(d[0], d[1], d[2], d[3], d[4], thr, C, top_k, optimistic=optimistic)
     torch.cuda.synchronize()
-    print("%-40s %s status=%d kept=%s  %.3f ms" % (name, "OK" if ok else "FAIL", int(status.item()), kc[:4], (time.perf_counter() - t0) / 5 * 1e3), flush=True)
+    print("%-40s %s status=%d kept=%s  %.3f ms" % (name + redo, "OK" if ok else "FAIL", int(status.item()), kc[:4], (time.perf_counter() - t0) / 5 * 1e3), flush=True)
     return ok
 
 
@@ -71,5 +78,11 @@ if __name__ == "__main__":
     allok &= check("untame box -> fallback", 2, 20000, 1, seed=11, n=[3000, 2000], untame=True)
     allok &= check("1 class top_k 100", 2, 20000, 1, seed=12, n=[5000, 2000], top_k=100)
     allok &= check("4 classes 60000 (one class > 16384)", 1, 70000, 4, seed=13)
+    allok &= check("prefix: big boxes keep < top_k -> redo", 2, 30000, 1, seed=14, wh=(0.2, 0.6), thr=0.3, top_k=100)
+    allok &= check("prefix: same, optimistic 20 classes", 2, 30000, 20, seed=15, wh=(0.3, 0.7), thr=0.2, top_k=600, optimistic=True)
+    allok &= check("prefix: 3 distinct scores (no cut)", 2, 30000, 4, seed=16, top_k=50, ties=3)
+    allok &= check("prefix: 1000 distinct scores", 2, 60000, 80, seed=17, top_k=300, ties=1000)
+    allok &= check("prefix: ragged counts", 3, 40000, 10, seed=18, n=[40000, 3000, 9000], top_k=200)
+    allok &= check("prefix: top_k 3000", 2, 100000, 80, seed=19, top_k=3000)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)

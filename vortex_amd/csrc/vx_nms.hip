@@ -1716,6 +1716,141 @@ __global__ __launch_bounds__(1024) void vx_k_topk_select(const u64 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// top_k on large inputs: greedy NMS decides a box from higher-scoring boxes only, so the kept boxes among ANY
+// score-prefix S of an image's candidates (every candidate outside S scores below every candidate inside) are
+// exactly the kept boxes of the full run that lie in S -- and they come first in the output order.  If S yields at
+// least top_k kept boxes, the first top_k of them ARE the result, whatever follows S.
+//   vx_k_prefix_thr     : one workgroup per image picks a score threshold from a strided sample of 4096 scores (its
+//                         r-th best, r chosen so that about vx_prefix_target(top_k) candidates pass; exact radix
+//                         select of the sample in LDS).  Any threshold gives a valid prefix -- the sample only aims it.
+//   vx_k_prefix_compact : all candidates whose descending-score key is at most the threshold (equal scores stay
+//                         together: a true prefix) -> the image's list, in any order (the NMS sorts)
+// vx_k_nms_image then runs on the list.  An image whose prefix keeps fewer than top_k boxes, or outgrows the list, is
+// redone from all its candidates by the paths behind that kernel.  (Class ids are validated for the candidates that
+// take part; the others cannot influence the result.)
+#define VX_PREFIX_CAP VX_SORT_CHMAX
+#define VX_PREFIX_SAMPLE 4096
+#define VX_PREFIX_CHUNK 8192
+__host__ __device__ __forceinline__ int vx_prefix_target(int top_k) {
+    int m = 4 * top_k;
+    return m < 2048 ? 2048 : (m > VX_PREFIX_CAP / 2 ? VX_PREFIX_CAP / 2 : m);
+}
+
+__global__ __launch_bounds__(1024) void vx_k_prefix_thr(const float *__restrict__ scores, const int *__restrict__ counts,
+                                                       vx_nms_params p, unsigned *__restrict__ pthr, int *__restrict__ pm) {
+    __shared__ unsigned s_key[VX_PREFIX_SAMPLE];
+    __shared__ int s_h[4096];
+    __shared__ int s_wtot[16];
+    __shared__ int s_T, s_before;
+    const int b = blockIdx.x, lane = vx_lane(), wave = threadIdx.x >> 6;
+    const int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
+    const int want = vx_prefix_target(p.top_k);
+    // pm[b]: -1 = no prefix for this image, else the compaction's cursor (starts at 0)
+    if (n <= 2 * want || n <= VX_SORT_CHMAX / 4) {   // small enough as it is
+        if (threadIdx.x == 0) pm[b] = -1;
+        return;
+    }
+    const float *sc = scores + (long long)b * p.cap;
+    float v[VX_PREFIX_SAMPLE / 1024];
+#pragma unroll
+    for (int q = 0; q < VX_PREFIX_SAMPLE / 1024; ++q) {
+        const int j = threadIdx.x + q * 1024;
+        v[q] = sc[(int)(((long long)j * n) / VX_PREFIX_SAMPLE)];
+    }
+#pragma unroll
+    for (int q = 0; q < VX_PREFIX_SAMPLE / 1024; ++q) s_key[threadIdx.x + q * 1024] = vx_desc_key(v[q]);
+    // rank (1-based) of the threshold inside the sample: an eighth above the aim, so that a sample that runs a little
+    // optimistic still yields enough candidates
+    int r = (int)(((long long)want * 9 * VX_PREFIX_SAMPLE) / ((long long)n * 8)) + 3;
+    if (r > VX_PREFIX_SAMPLE) r = VX_PREFIX_SAMPLE;
+    unsigned prefix = 0;
+    int before = 0, shift = 32;
+    for (int level = 0; level < 3; ++level) {        // 12 + 12 + 8 bits, most significant first
+        const int bits = level < 2 ? 12 : 8;
+        const int hi_shift = shift;
+        shift -= bits;
+        for (int i = threadIdx.x; i < 4096; i += 1024) s_h[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < VX_PREFIX_SAMPLE / 1024; ++q) {
+            const unsigned key = s_key[threadIdx.x + q * 1024];
+            if (hi_shift == 32 || (key >> hi_shift) == prefix) atomicAdd(&s_h[(key >> shift) & ((1u << bits) - 1u)], 1);
+        }
+        __syncthreads();
+        int hv[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hv[q] = s_h[threadIdx.x * 4 + q]; tot += hv[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int run = before + incl - tot;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_wtot[w2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (run < r && r <= run + hv[q]) { s_T = threadIdx.x * 4 + q; s_before = run; }
+            run += hv[q];
+        }
+        __syncthreads();
+        prefix = (prefix << bits) | (unsigned)s_T;
+        before = s_before;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { pthr[b] = prefix; pm[b] = 0; }
+}
+
+__global__ __launch_bounds__(1024) void vx_k_prefix_compact(const float *__restrict__ scores, const int *__restrict__ counts,
+                                                           vx_nms_params p, const unsigned *__restrict__ pthr,
+                                                           int *__restrict__ plist, int *__restrict__ pm) {
+    const int b = blockIdx.y, lane = vx_lane();
+    const int n = counts ? vx_clamp_count(counts[b], p.cap) : p.cap;
+    const int i0 = blockIdx.x * VX_PREFIX_CHUNK;
+    // (pm[b] >= 0 is the compaction cursor other workgroups are already adding to: only its sign is read here)
+    if (i0 >= n || __hip_atomic_load(&pm[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return;
+    const float *sc = scores + (long long)b * p.cap;
+    const unsigned thr = pthr[b];
+    int *pl = plist + (long long)b * VX_PREFIX_CAP;
+    __shared__ int s_wcnt[16];
+    __shared__ int s_base;
+    float v[VX_PREFIX_CHUNK / 1024];
+#pragma unroll
+    for (int q = 0; q < VX_PREFIX_CHUNK / 1024; ++q) {
+        const int i = i0 + q * 1024 + threadIdx.x;
+        v[q] = i < n ? sc[i] : 0.0f;
+    }
+    // members of this thread, the wave, the workgroup: ONE global atomic per workgroup reserves the chunk's range
+    // (a returning atomic per wave, ~1 300 per image on one word, took 0.26 ms on the 100 000-box batch)
+    const int wave = threadIdx.x >> 6;
+    unsigned inm = 0;
+#pragma unroll
+    for (int q = 0; q < VX_PREFIX_CHUNK / 1024; ++q) {
+        const int i = i0 + q * 1024 + threadIdx.x;
+        if (i < n && vx_desc_key(v[q]) <= thr) inm |= 1u << q;
+    }
+    const int mine = __popc(inm);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) s_wcnt[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int c = s_wcnt[w2]; s_wcnt[w2] = tot; tot += c; }
+        s_base = tot ? atomicAdd(&pm[b], tot) : 0;
+    }
+    __syncthreads();
+    int pos = s_base + s_wcnt[wave] + incl - mine;
+#pragma unroll
+    for (int q = 0; q < VX_PREFIX_CHUNK / 1024; ++q) {
+        if ((inm >> q) & 1u) {
+            if (pos < VX_PREFIX_CAP) pl[pos] = i0 + q * 1024 + threadIdx.x;       // beyond the list: the image is redone from all candidates
+            ++pos;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Whole NMS of one image in ONE workgroup (capacity <= VX_SORT_CHMAX): keys are built and sorted in
 // LDS, the class-offset boxes gathered into sorted order, every class segment swept (one wave per
 // small segment, the whole workgroup per large one; segment bounds come from 64-ary searches of the
@@ -1743,6 +1878,8 @@ struct vx_image_args {
     u64 *stamps;      // [B][8] shader-clock stamps of the phases of block b, or nullptr (set while vx_profile_enable is on)
     vx_bm_ws bm;      // bitmask path (vx_nms_bm.h): large segments are exported instead of swept here when bm_on != 0
     int bm_on;
+    const int *plist; // optional [B][VX_PREFIX_CAP]: score-prefix of an image's candidates (vx_k_prefix_select) ...
+    const int *pm;    // ... [B] its length, or -1: use all candidates
 };
 
 // An image with <= 64 candidates (the common case at the shipped score threshold 0.9: ~10 per image) is one
@@ -1825,8 +1962,10 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
 #define VX_IMG_MERGE_PER_THREAD 8        // positions of the run merge whose run index a thread keeps in registers
 // Tail of the single-launch kernel (also run by vx_k_bm_finish for an image whose large segments went through the
 // bitmask path): the kept keys of all segments -> global score order (run merge in LDS, or a second sort) -> outputs.
+// n_redo > 0: the image was processed from a score-prefix list; when fewer than top_k boxes were kept it is handed to the
+// paths behind this kernel (sel[b] = n_redo, its full candidate count) instead of being written.
 __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int n, int nseg, bool merge, u64 *sk,
-                                              int *s_gcnt, int *s_count2p, int rbits) {
+                                              int *s_gcnt, int *s_count2p, int rbits, int n_redo) {
     const vx_nms_params &p = a.p;
     const int nt = blockDim.x, wave = threadIdx.x >> 6, lane = vx_lane();
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
@@ -1905,6 +2044,15 @@ __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int
         vx_bitonic_sort_lds(sk, npad2, 0, 2, npad2);
     }
     VX_STAMP(6);
+    if (n_redo > n && p.top_k > 0 && n2 < p.top_k) {        // the score prefix kept too few boxes: redo from all candidates
+        if (threadIdx.x == 0) {
+            a.sel[b] = n_redo;
+            a.keep_counts[b] = 0;
+            if (a.defer) atomicOr(a.status, VX_STATUS_DEFERRED);
+            vx_status_or(a.status, rbits);
+        }
+        return;
+    }
     int nk = n2;
     if (p.top_k > 0) nk = min(nk, p.top_k);
     nk = min(nk, p.out_cap);
@@ -1936,7 +2084,11 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
     const vx_nms_params &p = a.p;
     const int b = blockIdx.x, nt = blockDim.x;
-    const int n = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    const int n_all = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    // score-prefix list (top_k on a large input, see vx_k_prefix_select): this kernel works on the list only
+    const int pmb = a.pm ? a.pm[b] : -1;
+    const int *pl = (pmb > 0 && pmb <= VX_PREFIX_CAP) ? a.plist + (long long)b * VX_PREFIX_CAP : nullptr;
+    const int n = pl ? pmb : n_all;
     if (a.bm_on && threadIdx.x == 0) { a.bm.pend[2 * b] = 0; a.bm.pend[2 * b + 1] = 0; }
     if (a.sel) {                                     // capacity beyond the LDS-resident sort: only images that fit
         const bool big = n > a.n_max;
@@ -1950,7 +2102,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         if (threadIdx.x == 0) a.keep_counts[b] = 0;
         return;
     }
-    if (n <= 64) {                                   // before any barrier: waves 1.. leave, wave 0 needs none
+    if (n <= 64 && !pl) {                            // before any barrier: waves 1.. leave, wave 0 needs none
         if (threadIdx.x < 64) vx_nms_image_small(a, b, n);
         return;
     }
@@ -1962,9 +2114,10 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     for (int i = threadIdx.x; i < npad; i += nt) {
         u64 key = VX_KEY_SENTINEL;
         if (i < n) {
-            long long c = a.cls[ib + i];
+            const int idx = pl ? pl[i] : i;
+            long long c = a.cls[ib + idx];
             if (c < 0 || c >= p.n_classes) { bad = true; c = c < 0 ? 0 : p.n_classes - 1; }
-            key = vx_key1((int)c, a.scores[ib + i], i);
+            key = vx_key1((int)c, a.scores[ib + idx], idx);
         }
         sk[i] = key;
     }
@@ -2055,7 +2208,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     const int nbig = min(s_nbig, VX_SWEEP_MAXBIG);
     // bitmask path: a large tame segment is laid out by position and registered for vx_k_bm_pairs; vx_k_bm_finish then
     // resolves it from its edge list and runs this kernel's tail for the image (needs the ordered-run bookkeeping)
-    const bool bm_ok = a.bm_on && merge && T.fast;
+    const bool bm_ok = a.bm_on && merge && T.fast && !pl;      // (a prefix image must be decided here: it may have to be redone)
     for (int q = 0; q < nbig; ++q) {
         const int lo = s_big[q][0], len = s_big[q][1];
         int *kc = merge ? segk + s_big[q][2] : nullptr;
@@ -2080,7 +2233,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         }
         return;
     }
-    vx_image_tail(a, b, n, nseg, merge, sk, s_gcnt, &s_count2, s_rbits);
+    vx_image_tail(a, b, n, nseg, merge, sk, s_gcnt, &s_count2, s_rbits, pl ? n_all : 0);
 #undef VX_STAMP
 }
 
@@ -2117,7 +2270,7 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
         }
     }
     __syncthreads();
-    vx_image_tail(a, b, n, nseg, true, sk, s_gcnt, &s_count2, 0);
+    vx_image_tail(a, b, n, nseg, true, sk, s_gcnt, &s_count2, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2142,6 +2295,8 @@ struct vx_nms_ws {
     int *part_runs;                                           // [B][VX_PART_MAX_CLASSES + 1] boundaries of the kept runs
     vx_bm_ws bm;                                              // bitmask path (capacities beyond the single-launch kernel only)
     int bm_on;
+    int *plist, *pm;                                          // score-prefix lists (top_k; same capacities)
+    unsigned *pthr;
     size_t bytes;
 };
 
@@ -2183,6 +2338,11 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
         w.bm.recs = (vx_bm_rec *)(p + off); off += vx_align256n(n * sizeof(vx_bm_rec));
         w.bm.edges = (unsigned *)(p + off); off += vx_align256n(n * VX_BM_ECAP * sizeof(unsigned));
         w.bm.edges2 = (unsigned *)(p + off); off += vx_align256n(n * VX_BM_ECAP * sizeof(unsigned));
+        w.plist = (int *)(p + off); off += vx_align256n((size_t)B * VX_PREFIX_CAP * sizeof(int));
+        w.pm = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+        w.pthr = (unsigned *)(p + off); off += vx_align256n((size_t)B * sizeof(unsigned));
+    } else {
+        w.plist = nullptr; w.pm = nullptr; w.pthr = nullptr;
     }
     w.bytes = off;
     return w;
@@ -2259,9 +2419,20 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.counts = d_counts; a.sbox = w.sbox; a.sarea = w.sarea; a.keys2 = w.keys2;
         a.keep_idx = (long long *)d_keep_idx; a.out_det = d_out_det; a.keep_counts = d_keep_counts;
         a.status = d_status; a.stamps = vx_prof_on ? w.stamps : nullptr; a.seg = w.seg; a.segk = w.segk;   // phase clocks only while profiling
-        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only && !partitioned;
+        // the optimistic call stops behind this kernel unless classes are declared (then the class-partitioned path is part
+        // of the bet) -- and always when a top_k lets the score prefix do the work: an image it cannot finish is deferred
+        a.sel = all_fit ? nullptr : w.sel; a.n_max = VX_SORT_CHMAX; a.defer = small_only && (!partitioned || top_k > 0);
         a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
         a.bm = w.bm; a.bm_on = w.bm_on;
+        a.plist = nullptr; a.pm = nullptr;
+        if (!all_fit && top_k > 0) {                 // top_k on a large input: score prefix first (see vx_k_prefix_select)
+            vx_prof_begin(VX_PROF_NMS_KEYS, st);
+            hipLaunchKernelGGL(vx_k_prefix_thr, dim3(B), dim3(1024), 0, st, d_scores, d_counts, p, w.pthr, w.pm);
+            hipLaunchKernelGGL(vx_k_prefix_compact, dim3((capacity + VX_PREFIX_CHUNK - 1) / VX_PREFIX_CHUNK, B), dim3(1024), 0, st,
+                               d_scores, d_counts, p, w.pthr, w.plist, w.pm);
+            vx_prof_end(VX_PROF_NMS_KEYS, st);
+            a.plist = w.plist; a.pm = w.pm;
+        }
         if (w.bm_on && hipMemsetAsync(w.bm.counters, 0, VX_BM_COUNTER_BYTES, st) != hipSuccess) return VX_ERR_LAUNCH;
         const int lds_keys = all_fit ? npad_cap : VX_SORT_CHMAX;
         int threads = lds_keys >= 1024 ? 1024 : 256;
@@ -2299,7 +2470,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         vx_prof_end(VX_PROF_BM_SCAN, st);
         return VX_OK;
     };
-    if (small_only && !partitioned) {
+    if (small_only && (!partitioned || top_k > 0)) {
         if (bm_launch(nullptr) != VX_OK) return VX_ERR_LAUNCH;
         return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
     }
