@@ -30,8 +30,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-CONFIG_NAMES = ("fpn_ssd_640_b64", "retinaface_640_b128", "nms_stress_100k_b32_top300", "yolo416_b256_dense",
-                "yolo416_b256_resize720p")
+CONFIG_NAMES = ("fpn_ssd_640_b64", "retinaface_640_b128", "nms_stress_100k_b32_top300", "nms_stress_100k_b32_all",
+                "yolo416_b256_dense", "yolo416_b256_resize720p", "yolo416_b1_latency")
 S, C = 416, 80
 R = 10647
 ROW_BYTES = (5 + C) * 4
@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--configs", default="all",
                     help="N=1 only: the other BASELINE configs measured as sub-records of the line: 'all', 'none' or a "
                          "comma-separated list of " + ", ".join(CONFIG_NAMES))
+    ap.add_argument("--repeats", type=int, default=5, help="repeats of the timed region (median reported)")
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight: 1 = synchronous API call per step (forward()), 2 = forward_async(): "
                          "the launches of step i+1 are enqueued before the results of step i are collected")
@@ -273,12 +274,17 @@ def main():
     profile = not args.no_profile
     dom = "vx_k_yolo_decode_rows" if args.unfused else "vx_k_yolo_fused"
     if profile:
-        L.profile_enable(max(args.steps * 4, 16), only=[dom])
-    barrier()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+        L.profile_enable(max(args.steps, 16) * 42, only=[dom])   # one launch of the dominant kernel per step, <= 40 repeats
+    # The timed region (exactly --steps steps between two barriers) is repeated: `value` is the MEDIAN repeat, the line
+    # carries min / max (`spread`).  One rank: at least 5 repeats and 0.3 s of timed work; several ranks: 5 repeats each,
+    # every repeat bracketed by the barrier, the slowest rank's time counting for it.
+    rep_dt = []
+    while len(rep_dt) < args.repeats or (world == 1 and sum(rep_dt) < 0.3 and len(rep_dt) < 40):
+        barrier()
+        t0 = time.perf_counter()
+        out = run_steps(args.steps)
+        barrier()
+        rep_dt.append(time.perf_counter() - t0)
     kern = L.profile_read() if profile else {}
     if profile:
         L.profile_enable(max(args.steps * 4, 16))          # untimed pass: every kernel family
@@ -336,13 +342,15 @@ def main():
         del graphed
         post = post_full
 
-    rank_dt = [dt]
+    per_rank = [rep_dt]
     if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor(rep_dt, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        rank_dt = [float(v.item()) for v in allt]
-        dt = max(rank_dt)                                   # whole-job time = the slowest rank
+        per_rank = [[float(v) for v in a_.tolist()] for a_ in allt]
+    job_dt = sorted(max(r[i] for r in per_rank) for i in range(len(rep_dt)))     # whole-job time of a repeat = its slowest rank
+    dt = job_dt[len(job_dt) // 2]
+    rank_dt = [sorted(r)[len(r) // 2] for r in per_rank]
 
     result = None
     if rank == 0:
@@ -384,6 +392,10 @@ def main():
             "per_rank_images_per_s": [round(B * args.steps / t_, 1) for t_ in rank_dt],
             "step_ms_min_max_over_ranks": [round(min(rank_dt) / args.steps * 1e3, 4), round(max(rank_dt) / args.steps * 1e3, 4)],
             "timed_region_ms": round(dt * 1e3, 2),
+            "spread": {"repeats": len(job_dt), "median_ms_per_step": round(dt / args.steps * 1e3, 4),
+                       "min_ms_per_step": round(job_dt[0] / args.steps * 1e3, 4),
+                       "max_ms_per_step": round(job_dt[-1] / args.steps * 1e3, 4),
+                       "note": "every repeat = exactly --steps steps between two barriers; value = the median repeat"},
             "pipeline_hbm": {"algorithmic_bytes_per_step": pipe_bytes,
                              "achieved_GBps_per_gpu": round(pipe_bytes * args.steps / dt / 1e9, 1),
                              "frac_of_8TBps": round(pipe_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
