@@ -314,7 +314,7 @@ def latency_cfg(steps=200, warmup=20, cpu_budget=4.0):
     return rec
 
 
-def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
+def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0, variants=True):
     """kind = 'dense' (score_thr 0.06) or 'resize720p' (720x1280 frames resized inside the pre-process)."""
     import bench
     import vortex_amd as V
@@ -353,12 +353,12 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0):
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.2}}
     if kind == "resize720p":
-        rec["roofline"] = _roof("vx_k_resize_fast (reported as vx_k_normalize/resize)", kern["vx_k_normalize/resize"],
-                                B * (3 * 720 * 1280 + 12 * S * S), tag, "vx_k_resize_fast")
+        rec["roofline"] = _roof("vx_k_resize_fast<true> (reported as vx_k_normalize/resize)", kern["vx_k_normalize/resize"],
+                                B * (3 * 720 * 1280 + 12 * S * S), tag, "vx_k_resize_fast<true>")
     else:
         rec["roofline"] = _roof("vx_k_yolo_fused", kern["vx_k_yolo_fused"], B * bench.ALGO_BYTES_DECODE + 32 * cand, tag)
     rec["nms"] = _nms_record(_iou_tests(fn), sum(kern.get(k, 0.0) for k in NMS_KERNELS))
-    if kind == "resize720p":
+    if kind == "resize720p" and variants:
         # the letterbox mode of the same kernel (aspect kept: 416 x 234 of the 416 x 416 output is resized, the rest is
         # the pad value) and the plain u8 -> u8 resize of runtime.resize_batch, kernel time only
         def _kernel_ms(f):
@@ -411,12 +411,13 @@ CONFIGS = {
     "yolo416_b1_latency": lambda **kw: latency_cfg(**kw),
     "yolo416_b256_dense": lambda **kw: yolo_cfg("dense", **kw),
     "yolo416_b256_resize720p": lambda **kw: yolo_cfg("resize720p", **kw),
+    "yolo416_b256_resize720p_only": lambda **kw: yolo_cfg("resize720p", variants=False, **kw),   # profiling: the stretch kernel alone
 }
 
 
 def run_configs(names=None, cpu=True):
     out = {}
-    for name in (names or CONFIGS):
+    for name in (names or [n for n in CONFIGS if not n.endswith("_only")]):
         kw = {} if cpu else {"cpu_budget": 0}
         try:
             out[name] = CONFIGS[name](**kw)
@@ -429,8 +430,8 @@ def run_configs(names=None, cpu=True):
 if __name__ == "__main__":
     alias = {"ssd": "fpn_ssd_640_b64", "retinaface": "retinaface_640_b128", "stress": "nms_stress_100k_b32_top300",
              "dense": "yolo416_b256_dense", "resize": "yolo416_b256_resize720p", "stress_all": "nms_stress_100k_b32_all",
-             "b1": "yolo416_b1_latency"}
+             "b1": "yolo416_b1_latency", "resize_only": "yolo416_b256_resize720p_only"}
     args = [a for a in sys.argv[1:] if a != "--no-cpu"]
-    which = [alias.get(a, a) for a in args] or list(CONFIGS)
+    which = [alias.get(a, a) for a in args] or None
     for k, v in run_configs(which, cpu="--no-cpu" not in sys.argv).items():
         print(json.dumps({"config": k, **v}), flush=True)

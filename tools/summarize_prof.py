@@ -23,13 +23,27 @@ def one(pattern):
     return f[-1] if f else None      # newest: gpurun merges every call's files into gpurun_out/
 
 
-def kname(full):
-    """'void vx_k_yolo_fused<2, true>(vx_fused_params, ...)' -> 'vx_k_yolo_fused' (rocprofv3 prints the
-    return type and template arguments of template kernels)."""
+def kname_full(full):
+    """'void vx_k_resize_fast<true>(vx_resize_params, ...)' -> 'vx_k_resize_fast<true>': the instantiated kernel, i.e.
+    the name up to the parenthesis that opens the argument list (template arguments kept: two instantiations of one
+    template are two kernels with their own byte counts and durations)."""
     n = full.strip().strip('"')
     if n.startswith("void "):
         n = n[5:]
-    return n.split("(")[0].split("<")[0]
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return n[:i].strip()
+    return n
+
+
+def kname(full):
+    """the template's name without its arguments"""
+    return kname_full(full).split("<")[0]
 
 
 def pmc(path, counter):
@@ -38,8 +52,17 @@ def pmc(path, counter):
         return {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+            agg[kname_full(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    out = {k: sum(v) / len(v) for k, v in agg.items()}
+    # a template with ONE instantiation in the run is also reachable by its bare name (the bench looks kernels up by
+    # that); with several instantiations there is no such alias: their averages must not be pooled
+    bare = collections.defaultdict(list)
+    for k in out:
+        bare[k.split("<")[0]].append(k)
+    for b, ks in bare.items():
+        if len(ks) == 1 and b not in out:
+            out[b] = out[ks[0]]
+    return out
 
 
 def main(src, tag, rnd, workload, dominant=None):
