@@ -240,9 +240,14 @@ def main():
             inp = decoded
         if args.allgather:
             packed, meta = post.forward_device(inp, sthr, ithr)
-            return x, parallel.allgather_detections(packed, meta, B)
+            t_ag = time.perf_counter()
+            res = parallel.allgather_detections(packed, meta, B)     # phase 1 waits for this step's GPU work (count D2H)
+            ag_s[0] += time.perf_counter() - t_ag
+            return x, res
         pend = post.forward_async(inp, sthr, ithr)          # counts land in pinned host memory, not awaited
         return x, pend if args.depth > 1 else pend.result()
+
+    ag_s = [0.0]            # host time inside allgather_detections (includes the wait for the step's kernels)
 
     def run_steps(n):
         """n full steps; every step's per-image tuple is materialised before this returns."""
@@ -279,12 +284,14 @@ def main():
     # carries min / max (`spread`).  One rank: at least 5 repeats and 0.3 s of timed work; several ranks: 5 repeats each,
     # every repeat bracketed by the barrier, the slowest rank's time counting for it.
     rep_dt = []
+    ag_s[0] = 0.0
     while len(rep_dt) < args.repeats or (world == 1 and sum(rep_dt) < 0.3 and len(rep_dt) < 40):
         barrier()
         t0 = time.perf_counter()
         out = run_steps(args.steps)
         barrier()
         rep_dt.append(time.perf_counter() - t0)
+    ag_ms_per_step = ag_s[0] / (len(rep_dt) * args.steps) * 1e3
     kern = L.profile_read() if profile else {}
     if profile:
         L.profile_enable(max(args.steps * 4, 16))          # untimed pass: every kernel family
@@ -342,6 +349,12 @@ def main():
         del graphed
         post = post_full
 
+    rank_devices = [local]
+    if dist is not None:
+        td = torch.tensor([local], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+        alld = [torch.zeros_like(td) for _ in range(world)]
+        dist.all_gather(alld, td)
+        rank_devices = [int(v.item()) for v in alld]
     per_rank = [rep_dt]
     if dist is not None:
         t = torch.tensor(rep_dt, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -389,6 +402,8 @@ def main():
                        "hip_streams": 2 if two_streams else 1},
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "single process",
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
+            "rank_devices": rank_devices,
+            "allgather_ms_per_step": round(ag_ms_per_step, 4) if args.allgather else None,
             "per_rank_images_per_s": [round(B * args.steps / t_, 1) for t_ in rank_dt],
             "step_ms_min_max_over_ranks": [round(min(rank_dt) / args.steps * 1e3, 4), round(max(rank_dt) / args.steps * 1e3, 4)],
             "timed_region_ms": round(dt * 1e3, 2),

@@ -60,9 +60,11 @@ def test_allgather_detections_over_rccl_world1():
             p.kill()
 
 
-def test_bench_spawns_its_own_ranks_without_a_launcher():
+@pytest.mark.parametrize("allgather", [False, True])
+def test_bench_spawns_its_own_ranks_without_a_launcher(allgather):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two fresh rank processes itself (before
-    any GPU call in the parent); on a one-GPU box they share the GPU over gloo and the line says so."""
+    any GPU call in the parent); on a one-GPU box they share the GPU over gloo and the line says so.  With --allgather
+    every step ends in parallel.allgather_detections over the two ranks."""
     import json
     import os
     import subprocess
@@ -70,7 +72,8 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--batch", "16", "--no-cpu-baseline", "--no-variants", "--configs", "none"],
+                          "--batch", "16", "--no-cpu-baseline", "--no-variants", "--configs", "none", "--repeats", "2"]
+                         + (["--allgather"] if allgather else []),
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -81,3 +84,6 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     assert rec["backend"] == ("rccl" if torch.cuda.device_count() >= 2 else "gloo")
     assert rec["config"]["global_batch"] == 32 and rec["value"] > 0
     assert rec["step_ms_min_max_over_ranks"][0] <= rec["step_ms_min_max_over_ranks"][1]
+    assert len(rec["rank_devices"]) == 2 and rec["spread"]["repeats"] >= 2
+    if allgather:              # the collective is rehearsed too (gloo stages the device tensors through the host)
+        assert rec["allgather_ms_per_step"] > 0 and "all-gather" in rec["config"]["parallelism"]

@@ -31,7 +31,15 @@ def _all_gather_flat(x: torch.Tensor, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     out = torch.empty((world * x.size(0),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     if dist.get_backend(group) == "gloo":
-        dist.all_gather(list(out.chunk(world, 0)), x.contiguous(), group=group)
+        if x.is_cuda:
+            # rehearsal on a box with fewer GPUs than ranks: gloo has no device all-gather, so the payload (a few KB per
+            # image) is staged through host tensors; the production path below never leaves the device
+            hx = x.contiguous().cpu()
+            hout = torch.empty((world * hx.size(0),) + tuple(hx.shape[1:]), dtype=hx.dtype)
+            dist.all_gather(list(hout.chunk(world, 0)), hx, group=group)
+            out.copy_(hout)
+        else:
+            dist.all_gather(list(out.chunk(world, 0)), x.contiguous(), group=group)
     else:
         dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
