@@ -1432,8 +1432,7 @@ template <int LDS_KEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
-    __shared__ union { vx_spatial_smem sp; vx_bm_prep_smem prep; } U;
-    vx_spatial_smem &SP = U.sp;
+    __shared__ vx_bm_prep_smem PREP;
     __shared__ int s_rbits;
     const int b = blockIdx.y, c = blockIdx.x;
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
@@ -1474,11 +1473,9 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
     int *kc = a.ordered ? a.hist + b * VX_PART_MAX_CLASSES + c : nullptr;     // the histogram has been consumed
     if (!big) {
         if (threadIdx.x < 64) vx_sweep_wave(sb, sa, sk, 0, len, T, k2, c2, a.iou_count, kc);
-    } else if (a.bm_on && T.fast && len > VX_BM_MIN && vx_bm_prep(U.prep, a.bm, b, lo, c, 1, sb, len)) {
+    } else if (a.bm_on && T.fast && vx_bm_prep(PREP, sk, a.bm, b, lo, c, 1, sb, len)) {
         // registered for vx_k_bm_pairs; vx_k_bm_scan emits the kept keys
-    } else if (vx_sweep_spatial(SP, sk, (size_t)(LDS_KEYS > VX_PART_SMALL ? VX_SORT_CHMAX * 8 : VX_PART_SMALL * 20), sb, len, T, p.top_k, a.iou_count)) {
-        vx_spatial_emit(SP, kseg, k2, c2, kc);
-    } else {
+    } else {                                         // untame boxes / threshold outside the bracket's range: chain sweep
         vx_sweep_async(A, sk, sb, len, T, p.top_k, a.iou_count);                       // the ring takes the keys' LDS
         vx_async_emit(A, kseg, k2, c2, kc);
     }
@@ -2213,7 +2210,8 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         const int lo = s_big[q][0], len = s_big[q][1];
         int *kc = merge ? segk + s_big[q][2] : nullptr;
         u64 *kd = merge ? k2 + lo : k2;
-        if (bm_ok && len > VX_BM_MIN && len <= VX_BM_MAXN && vx_bm_prep(U.prep, a.bm, b, lo, s_big[q][2], 0, sb + lo, len)) {
+        if (bm_ok && len > VX_BM_MIN && len <= VX_BM_MAXN && VX_BM_PREP_SCRATCH(len) <= a.lds_bytes &&
+            vx_bm_prep(U.prep, sk, a.bm, b, lo, s_big[q][2], 0, sb + lo, len)) {
             if (threadIdx.x == 0) { a.bm.img_exp[b * VX_BM_MAXEXP + s_nexp] = U.prep.si; ++s_nexp; }
             continue;
         }
@@ -2502,8 +2500,11 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         hipLaunchKernelGGL(vx_k_part_scatter, tiles, dim3(1024), 0, st, a);
         vx_prof_end(VX_PROF_NMS_KEYS, st);
         vx_prof_begin(VX_PROF_SWEEP, st);
-        // dynamic LDS: the segment's keys while sorting, then the sweep's scratch (spatial copy of the segment: 20 B per box)
-        hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), VX_PART_SMALL * 20, st, a);
+        // dynamic LDS: the segment's keys while sorting, then the scratch of the bitmask prep or the ring of the chain sweep
+        size_t small_lds = VX_PART_SMALL * sizeof(u64);
+        if (small_lds < VX_BM_PREP_SCRATCH(VX_PART_SMALL)) small_lds = VX_BM_PREP_SCRATCH(VX_PART_SMALL);
+        if (small_lds < vx_async_ring_bytes(8)) small_lds = vx_async_ring_bytes(8);
+        hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), small_lds, st, a);
         hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(n_classes, B), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
         vx_prof_end(VX_PROF_SWEEP, st);
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
