@@ -1428,8 +1428,10 @@ __global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
     }
 }
 
+// (512-thread variant: four workgroups per CU wanted -- 8 waves per SIMD, 64 registers; the chain-sweep fall-back spills
+// under that budget, the sort / gather / prep that every segment runs do not)
 template <int LDS_KEYS, int THREADS>
-__global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
     __shared__ vx_bm_prep_smem PREP;
@@ -1485,7 +1487,7 @@ __global__ __launch_bounds__(THREADS) void vx_k_part_sweep(vx_part_args a) {
 // Bitmask path, last step on the class-partitioned route: the registered segments are dealt round-robin to the
 // workgroups; each is resolved from its edge list (the chain sweep when the list overflowed) and its kept keys are
 // emitted exactly as vx_k_part_sweep would have done.
-__global__ __launch_bounds__(256) void vx_k_bm_scan(vx_part_args a) {
+__global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];             // ring of the chain sweep (fallback only)
     __shared__ union { vx_async_smem as; vx_bm_scan_smem sc; } U;
     const vx_nms_params &p = a.p;
