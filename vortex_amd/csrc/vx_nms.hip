@@ -1428,10 +1428,10 @@ __global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
     }
 }
 
-// (512-thread variant: four workgroups per CU wanted -- 8 waves per SIMD, 64 registers; the chain-sweep fall-back spills
+// (512-thread variant: three to four workgroups per CU wanted -- 7 waves per SIMD, 72 registers (64 are out of reach); the chain-sweep fall-back spills
 // under that budget, the sort / gather / prep that every segment runs do not)
 template <int LDS_KEYS, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) void vx_k_part_sweep(vx_part_args a) {
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_sweep(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
     __shared__ vx_bm_prep_smem PREP;
@@ -1513,107 +1513,185 @@ __global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Run merge (class-partitioned path, ordered emission): the kept keys of an image are n_classes ascending runs; a
-// second sort of all of them (log^2 passes) is replaced by  compact (runs made adjacent, boundaries R[b][0..NC])  and
-// ceil(log2 NC) merge rounds.  In round g (1, 2, 4, ...) the runs [2jg, (2j+1)g) and [(2j+1)g, (2j+2)g) are merged:
-// every key finds its place by one binary search in the sibling run (keys are unique: the index is part of the key).
-#define VX_RUNS_TILE 1024
+// Run merge (class-partitioned path, ordered emission): the kept keys of an image are n_classes ascending runs (run c
+// at keys2[segstart[c] ..), hist[b][c] keys).  Instead of a second sort of all of them, or log2(n_classes) rounds of
+// pairwise merges over global memory (round 2: five rounds + a compaction, 0.145 ms on the FPN-SSD batch, each round a
+// chain of ~11 dependent L2 reads per key), the output is cut into buckets by key VALUE:
+//   vx_k_runs_split : one workgroup per image.  A strided sample of the runs (every stride-th key
+//                     samples, at most 1024) is sorted in LDS; every (samples / buckets)-th sample is a splitter; a binary search per
+//                     (splitter, run) gives the part of every run that falls into each bucket, their sum the bucket's
+//                     place in the output.  A sample's rank is known to within one stride per run, so a bucket holds at
+//                     most VX_RUNS_BUCKET + 2 * n_classes * stride keys.
+//   vx_k_runs_bucket: one workgroup per (bucket, image): the bucket's keys -- a contiguous piece of every run -- are
+//                     gathered into LDS, sorted there, and the output rows are written (the second sort's epilogue).  A
+//                     bucket beyond the LDS buffer (possible with hundreds of classes and a long tail of ties in the
+//                     sample) is ranked key by key with binary searches over the other runs' pieces instead: slow, exact.
+// Keys are unique (the index is part of the key), so the order is total and the result equals the full sort's.
+#define VX_RUNS_BUCKET 2048            // keys per bucket aimed at
+#define VX_RUNS_MAXB 64                // buckets per image at most (more keys: larger buckets)
+#define VX_RUNS_PER_THREAD 8           // positions of a bucket per thread of vx_k_runs_bucket (512 threads)
+#define VX_RUNS_CAP (512 * VX_RUNS_PER_THREAD)   // keys a bucket merges in LDS (two buffers)
+#define VX_RUNS_SAMPLES 2048           // LDS sort size of the sample
 
-__device__ __forceinline__ bool vx_runs_load(const vx_part_args &a, const int *__restrict__ R, int b, int *s_R) {
-    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return false;      // finished by vx_k_nms_image / deferred
-    for (int c = threadIdx.x; c <= a.p.n_classes; c += blockDim.x) s_R[c] = R[b * (VX_PART_MAX_CLASSES + 1) + c];
-    __syncthreads();
-    return true;
+struct vx_runs_ws {
+    int *lb;       // [B][VX_RUNS_MAXB][VX_PART_MAX_CLASSES]: keys of run c below splitter j (j = 1 .. nb-1)
+    int *bstart;   // [B][VX_RUNS_MAXB + 1] first output position of every bucket; [nb] = total
+    int *nb;       // [B] buckets of the image (0: nothing to do here)
+    int *list;     // [B * VX_RUNS_MAXB] the call's buckets, (image << 8) | bucket, in any order ...
+    int *nlist;    // ... and their number (zeroed per call)
+};
+
+__device__ __forceinline__ bool vx_runs_skip(const vx_part_args &a, int b) {
+    return a.sel[b] == 0 || (a.defer && a.sel2[b] != 0);           // finished by vx_k_nms_image / deferred
 }
 
-// largest r in [0, NC) with s_R[r] <= o (o < s_R[NC]): the run that holds position o
-__device__ __forceinline__ int vx_runs_find(const int *s_R, int NC, int o) {
-    int lo = 0, hi = NC;                             // invariant: s_R[lo] <= o < s_R[hi]
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (s_R[mid] <= o) lo = mid; else hi = mid;
-    }
+// keys of the sorted run [p, p + n) below x
+__device__ __forceinline__ int vx_runs_lower(const u64 *__restrict__ p, int n, u64 x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (p[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
-__global__ __launch_bounds__(256) void vx_k_runs_compact(vx_part_args a, u64 *__restrict__ dst, int *__restrict__ R) {
-    __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
-    const int b = blockIdx.y;
-    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return;
+__global__ __launch_bounds__(1024) void vx_k_runs_split(vx_part_args a, vx_runs_ws rw, vx_epi_params ep) {
+    __shared__ __attribute__((aligned(16))) u64 sk[VX_RUNS_SAMPLES];
+    __shared__ int s_R[VX_PART_MAX_CLASSES], s_len[VX_PART_MAX_CLASSES], s_soff[VX_PART_MAX_CLASSES + 1];
+    __shared__ u64 s_spl[VX_RUNS_MAXB];
+    __shared__ int s_boff[VX_RUNS_MAXB + 1];
+    __shared__ int s_total, s_nsamp;
+    const int b = blockIdx.x, nt = blockDim.x, lane = vx_lane();
     const int NC = a.p.n_classes;
-    if (threadIdx.x < 64) {                          // exclusive scan of the kept counts (<= 256: 4 per lane)
-        const int lane = threadIdx.x;
-        const int *h = a.hist + b * VX_PART_MAX_CLASSES;
+    if (vx_runs_skip(a, b)) {
+        if (threadIdx.x == 0) rw.nb[b] = 0;
+        return;
+    }
+    const long long ob = (long long)b * a.p.npad_cap;
+    const u64 *k2 = a.keys2 + ob;
+    if (threadIdx.x < 64) {                          // run lengths, their sum (<= 256 runs: 4 per lane)
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane * 4 + q;
+            const int len = c < NC ? a.hist[b * VX_PART_MAX_CLASSES + c] : 0;
+            if (c < NC) { s_len[c] = len; s_R[c] = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c]; }
+            tot += len;
+        }
+        tot = vx_wave_sum_i(tot);
+        if (lane == 0) s_total = tot;
+    }
+    for (int j = threadIdx.x; j <= VX_RUNS_MAXB; j += nt) s_boff[j] = 0;
+    __syncthreads();
+    const int total = s_total;
+    int nk = total;
+    if (ep.top_k > 0) nk = min(nk, ep.top_k);
+    nk = min(nk, ep.out_cap);
+    if (threadIdx.x == 0) ep.keep_counts[b] = nk;
+    if (total == 0) {
+        if (threadIdx.x == 0) rw.nb[b] = 0;
+        return;
+    }
+    int nb = (total + VX_RUNS_BUCKET - 1) / VX_RUNS_BUCKET;
+    nb = min(nb, VX_RUNS_MAXB);
+    // sample: the middle key of every block of `stride` keys of every run (the last block may be short): a sample stands for
+    // the keys around it -- sampling block ENDS left the tails of all runs, n_classes * stride / 2 keys, to the last bucket
+    const int stride = max(16, (total + 1023) / 1024);
+    if (threadIdx.x < 64) {
         int v[4], tot = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { int c = lane * 4 + q; v[q] = c < NC ? h[c] : 0; tot += v[q]; }
+        for (int q = 0; q < 4; ++q) { const int c = lane * 4 + q; v[q] = c < NC ? (s_len[c] + stride - 1) / stride : 0; tot += v[q]; }
         int incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         int run = incl - tot;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { int c = lane * 4 + q; if (c <= NC) s_R[c] = run; run += v[q]; }
-        if (lane == 63) s_R[NC] = incl;
+        for (int q = 0; q < 4; ++q) { const int c = lane * 4 + q; if (c <= NC) s_soff[c] = run; run += v[q]; }
+        if (lane == 63) { s_soff[NC] = incl; s_nsamp = incl; }
     }
     __syncthreads();
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c <= NC; c += blockDim.x) R[b * (VX_PART_MAX_CLASSES + 1) + c] = s_R[c];
-    const int total = s_R[NC];
-    const long long ob = (long long)b * a.p.npad_cap;
-    const int *seg = a.segstart + b * (VX_PART_MAX_CLASSES + 1);
-    const int o1 = min(total, (int)(blockIdx.x + 1) * VX_RUNS_TILE);
-    for (int o = blockIdx.x * VX_RUNS_TILE + threadIdx.x; o < o1; o += blockDim.x) {
-        const int c = vx_runs_find(s_R, NC, o);
-        dst[ob + o] = a.keys2[ob + seg[c] + (o - s_R[c])];
+    const int nsamp = s_nsamp;                       // <= total / stride + n_classes <= 1280 < VX_RUNS_SAMPLES
+    const int npad = vx_next_pow2(max(nsamp, 1));
+    for (int i = threadIdx.x; i < npad; i += nt) {
+        u64 key = VX_KEY_SENTINEL;
+        if (i < nsamp) {
+            int lo = 0, hi = NC;                     // run of sample i: s_soff[lo] <= i < s_soff[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_soff[mid] <= i) lo = mid; else hi = mid; }
+            key = k2[s_R[lo] + min((i - s_soff[lo]) * stride + (stride >> 1), s_len[lo] - 1)];
+        }
+        sk[i] = key;
+    }
+    __syncthreads();
+    vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    if (nsamp == 0) nb = 1;
+    for (int j = 1 + threadIdx.x; j < nb; j += nt) s_spl[j] = sk[(int)(((long long)j * nsamp) / nb)];
+    __syncthreads();
+    // keys of every run below every splitter
+    int *lbt = rw.lb + (long long)b * VX_RUNS_MAXB * VX_PART_MAX_CLASSES;
+    for (int e = threadIdx.x; e < (nb - 1) * NC; e += nt) {
+        const int j = e / NC + 1, c = e - (j - 1) * NC;
+        const int lbv = vx_runs_lower(k2 + s_R[c], s_len[c], s_spl[j]);
+        lbt[j * VX_PART_MAX_CLASSES + c] = lbv;
+        if (lbv) atomicAdd(&s_boff[j], lbv);
+    }
+    __syncthreads();
+    int *bs = rw.bstart + b * (VX_RUNS_MAXB + 1);
+    for (int j = threadIdx.x; j <= nb; j += nt) bs[j] = j == nb ? total : s_boff[j];
+    if (threadIdx.x == 0) {
+        rw.nb[b] = nb;
+        const int at = atomicAdd(rw.nlist, nb);          // the buckets of the call, for vx_k_runs_bucket's bounded grid
+        for (int j = 0; j < nb; ++j) rw.list[at + j] = (b << 8) | j;
     }
 }
 
-// one key per thread: the binary search is a chain of dependent L2 reads, so the launch wants as many of them in
-// flight as it can get.  LAST: the final round writes the outputs (the second sort's epilogue) instead of the keys.
-// (A/B: a wave-cooperative search -- the places of a wave's first and last key by two 32-ary searches, the sibling keys
-// between them loaded once, every lane counting with shuffles: 3 dependent reads instead of 11 -- left the round at
-// 19.5 us on the FPN-SSD batch: the round is bound by the per-workgroup start-up chain, not by the search.)
-#define VX_MERGE_TILE 256
-template <bool LAST>
-__global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a, const u64 *__restrict__ src,
-                                                                u64 *__restrict__ dst, const int *__restrict__ R, int g,
-                                                                vx_epi_params ep) {
-    __shared__ int s_R[VX_PART_MAX_CLASSES + 1];
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_ws rw, vx_epi_params ep) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];         // [2 * VX_RUNS_CAP]
+    __shared__ int s_R[VX_PART_MAX_CLASSES], s_lo[VX_PART_MAX_CLASSES], s_hi[VX_PART_MAX_CLASSES], s_off[VX_PART_MAX_CLASSES + 1];
+    const int nt = blockDim.x, lane = vx_lane();
+    const int nlist = min(*rw.nlist, a.p.B * VX_RUNS_MAXB);
     const int NC = a.p.n_classes;
-    if (a.sel[b] == 0 || (a.defer && a.sel2[b] != 0)) return;      // finished by vx_k_nms_image / deferred
-    // most workgroups of the grid (sized for the capacity) lie behind the image's kept keys: they leave after one
-    // scalar load, before the boundary table and its barrier
-    const int total = R[b * (VX_PART_MAX_CLASSES + 1) + NC];
-    int nk = total;
-    if (LAST) {
-        if (ep.top_k > 0) nk = min(nk, ep.top_k);
-        nk = min(nk, ep.out_cap);
-        if (blockIdx.x == 0 && threadIdx.x == 0) ep.keep_counts[b] = nk;
-    }
-    if ((int)(blockIdx.x * VX_MERGE_TILE) >= total) return;
-    const int o = blockIdx.x * VX_MERGE_TILE + threadIdx.x;
+    // the call's buckets are dealt round-robin to a bounded grid (a grid over every possible bucket of every image is
+    // mostly workgroups that leave at once, and with 64 KiB of LDS each they queue behind one another)
+    for (int wi = blockIdx.x; wi < nlist; wi += gridDim.x) {
+    const int ent = rw.list[wi];
+    const int b = ent >> 8, j = ent & 255;
+    const int nb = rw.nb[b];
+    const int *bs = rw.bstart + b * (VX_RUNS_MAXB + 1);
+    const int o0 = bs[j], cnt = bs[j + 1] - o0;
+    const int nk = ep.keep_counts[b];
+    if (cnt <= 0 || o0 >= nk) continue;
+    __syncthreads();                                 // the previous bucket's LDS is free
     const long long ob = (long long)b * a.p.npad_cap;
-    const u64 *s = src + ob;
-    const u64 x_early = o < total ? s[o] : 0ull;     // requested before the table load: the two latencies overlap
-    vx_runs_load(a, R, b, s_R);
-    if (o >= total) return;
-    const int r = vx_runs_find(s_R, NC, o);
-    const int G = (r / g) & ~1;                      // groups of g runs; groups G and G + 1 are merged
-    const int a0 = s_R[min(G * g, NC)], m0 = s_R[min((G + 1) * g, NC)], b1 = s_R[min((G + 2) * g, NC)];
-    const bool second = o >= m0;
-    const u64 x = x_early;
-    int lo = second ? a0 : m0, hi = second ? m0 : b1;  // the sibling run: how many of its keys are below x
-    const int sib0 = lo;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (s[mid] < x) lo = mid + 1; else hi = mid;
+    const u64 *k2 = a.keys2 + ob;
+    const int *lbt = rw.lb + (long long)b * VX_RUNS_MAXB * VX_PART_MAX_CLASSES;
+    if (threadIdx.x < 64) {                          // the bucket's piece [lo, hi) of every run and the pieces' prefix
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane * 4 + q;
+            v[q] = 0;
+            if (c < NC) {
+                const int lo = j == 0 ? 0 : lbt[j * VX_PART_MAX_CLASSES + c];
+                const int hi = j == nb - 1 ? a.hist[b * VX_PART_MAX_CLASSES + c] : lbt[(j + 1) * VX_PART_MAX_CLASSES + c];
+                s_R[c] = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
+                s_lo[c] = lo; s_hi[c] = hi;
+                v[q] = hi - lo;
+            }
+            tot += v[q];
+        }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        int run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = lane * 4 + q; if (c <= NC) s_off[c] = run; run += v[q]; }
+        if (lane == 63) s_off[NC] = incl;
     }
-    const int pos = a0 + (o - (second ? m0 : a0)) + (lo - sib0);
-    if (!LAST) {
-        dst[ob + pos] = x;
-    } else if (pos < nk) {
-        const long long idx = (long long)(x & 0xFFFFFFFFull);
+    __syncthreads();
+    auto piece_of = [&](int i) __attribute__((always_inline)) -> int {      // s_off[c] <= i < s_off[c + 1] (empty pieces skipped)
+        int lo = 0, hi = NC;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+        return lo;
+    };
+    auto write_row = [&](int pos, u64 key) __attribute__((always_inline)) {
+        const long long idx = (long long)(key & 0xFFFFFFFFull);
         ep.keep_idx[(long long)b * ep.out_cap + pos] = idx;
         const float *det = ep.det + ((long long)b * ep.cap + idx) * ep.D;
         float *out = ep.out_det + ((long long)b * ep.out_cap + pos) * ep.D;
@@ -1622,6 +1700,51 @@ __global__ __launch_bounds__(VX_MERGE_TILE) void vx_k_runs_merge(vx_part_args a,
         } else {
             for (int q = 0; q < ep.D; ++q) out[q] = det[q];
         }
+    };
+    if (cnt <= VX_RUNS_CAP) {
+        // the bucket's pieces are sorted runs: merged pairwise in LDS, ceil(log2 n_classes) rounds, every key finds its place
+        // by one binary search in the sibling run (the routine of vx_k_nms_image's tail; a bitonic sort of the bucket
+        // took 0.22 ms on the FPN-SSD batch, ten times this)
+        u64 *src = sk, *dst = sk + VX_RUNS_CAP;
+        int rr[VX_RUNS_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < VX_RUNS_PER_THREAD; ++k) {
+            const int o = threadIdx.x + k * nt;
+            rr[k] = 0;
+            if (o < cnt) { const int c = piece_of(o); rr[k] = c; src[o] = k2[s_R[c] + s_lo[c] + (o - s_off[c])]; }
+        }
+        __syncthreads();
+        for (int lg = 0; (1 << lg) < NC; ++lg) {
+#pragma unroll
+            for (int k = 0; k < VX_RUNS_PER_THREAD; ++k) {
+                const int o = threadIdx.x + k * nt;
+                if (o < cnt) {
+                    const int G = (rr[k] >> lg) & ~1;    // groups of 2^lg runs; groups G and G + 1 are merged
+                    const int a0 = s_off[min(G << lg, NC)], m0 = s_off[min((G + 1) << lg, NC)], b1 = s_off[min((G + 2) << lg, NC)];
+                    const bool second = o >= m0;
+                    const u64 x = src[o];
+                    int lo2 = second ? a0 : m0, hi2 = second ? m0 : b1;
+                    const int sib0 = lo2;
+                    while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (src[mid] < x) lo2 = mid + 1; else hi2 = mid; }
+                    dst[a0 + (o - (second ? m0 : a0)) + (lo2 - sib0)] = x;
+                }
+            }
+            __syncthreads();
+            u64 *t = src; src = dst; dst = t;
+        }
+        const int rows = min(cnt, nk - o0);
+        for (int i = threadIdx.x; i < rows; i += nt) write_row(o0 + i, src[i]);
+    } else {
+        // beyond the LDS buffer: the place of a key = the keys below it in every run's piece
+        for (int i = threadIdx.x; i < cnt; i += nt) {
+            const int c = piece_of(i);
+            const u64 x = k2[s_R[c] + s_lo[c] + (i - s_off[c])];
+            int rank = i - s_off[c];
+            for (int c2 = 0; c2 < NC; ++c2)
+                if (c2 != c && s_hi[c2] > s_lo[c2]) rank += vx_runs_lower(k2 + s_R[c2] + s_lo[c2], s_hi[c2] - s_lo[c2], x);
+            if (o0 + rank < nk) write_row(o0 + rank, x);
+        }
+    }
     }
 }
 
@@ -2292,7 +2415,7 @@ static int vx_set_max_lds(vx_attr_cache &c, const void *kernel, int bytes) {
 struct vx_nms_ws {
     u64 *keys1; vx_f4 *sbox; float *sarea; u64 *keys2; int *count2; u64 *stamps; int *seg; int *segk; int *sel;
     int *part_hist, *part_cursor, *part_segstart, *sel2;      // class-partitioned path (hist and cursor are adjacent)
-    int *part_runs;                                           // [B][VX_PART_MAX_CLASSES + 1] boundaries of the kept runs
+    vx_runs_ws runs;                                          // bucket tables of the run merge (vx_k_runs_split)
     vx_bm_ws bm;                                              // bitmask path (capacities beyond the single-launch kernel only)
     int bm_on;
     int *plist, *pm;                                          // score-prefix lists (top_k; same capacities)
@@ -2318,7 +2441,12 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
     w.part_cursor = (int *)(p + off); off += vx_align256n((size_t)B * VX_PART_MAX_CLASSES * sizeof(int));
     w.part_segstart = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
     w.sel2 = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
-    w.part_runs = (int *)(p + off); off += vx_align256n((size_t)B * (VX_PART_MAX_CLASSES + 1) * sizeof(int));
+    w.runs.nb = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
+    w.runs.list = (int *)(p + off); off += vx_align256n((size_t)B * VX_RUNS_MAXB * sizeof(int));
+    w.runs.nlist = nullptr;                                   // = bm.counters + 2 (set below, zeroed with the counter block)
+    w.runs.bstart = (int *)(p + off); off += vx_align256n((size_t)B * (VX_RUNS_MAXB + 1) * sizeof(int));
+    w.runs.lb = (int *)(p + off);
+    if (npad_cap > VX_SORT_CHMAX) off += vx_align256n((size_t)B * VX_RUNS_MAXB * VX_PART_MAX_CLASSES * sizeof(int));
     // Bitmask path (vx_nms_bm.h).  Only capacities beyond the single-launch kernel carry it: below that the whole NMS
     // is one launch and stays so.
     w.bm = vx_bm_ws();
@@ -2329,6 +2457,7 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
         w.bm.max_segs = B * msi;
         w.bm.max_items = B * (npad_cap / 64 + msi);
         w.bm.counters = (int *)(p + off); off += VX_BM_COUNTER_BYTES;
+        w.runs.nlist = w.bm.counters + 2;
         w.bm.segs = (vx_bm_seg *)(p + off); off += vx_align256n((size_t)w.bm.max_segs * sizeof(vx_bm_seg));
         w.bm.ecount = (int *)(p + off); off += vx_align256n((size_t)w.bm.max_segs * sizeof(int));
         w.bm.item_seg = (int *)(p + off); off += vx_align256n((size_t)w.bm.max_items * sizeof(int));
@@ -2550,18 +2679,13 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     } else if (!run_merge) {
         rc = vx_sort_launch(w.keys2, w.count2, 0, B, npad_cap, 2, ep, st);
     } else {
-        {                                              // kept runs of every image left by vx_k_nms_image: keys2 -> keys1 -> keys2 ...
-            dim3 tiles((capacity + VX_RUNS_TILE - 1) / VX_RUNS_TILE, B), mtiles((capacity + VX_MERGE_TILE - 1) / VX_MERGE_TILE, B);
-            hipLaunchKernelGGL(vx_k_runs_compact, tiles, dim3(256), 0, st, pa, w.keys1, w.part_runs);
-            u64 *src = w.keys1, *dst = w.keys2;
-            for (int g = 1; g < n_classes; g <<= 1) {
-                if (2 * g < n_classes)
-                    hipLaunchKernelGGL(vx_k_runs_merge<false>, mtiles, dim3(VX_MERGE_TILE), 0, st, pa, src, dst, w.part_runs, g, ep);
-                else
-                    hipLaunchKernelGGL(vx_k_runs_merge<true>, mtiles, dim3(VX_MERGE_TILE), 0, st, pa, src, dst, w.part_runs, g, ep);
-                u64 *t = src; src = dst; dst = t;
-            }
-        }
+        static vx_attr_cache bucket_attr_set;
+        if (vx_set_max_lds(bucket_attr_set, (const void *)vx_k_runs_bucket, 2 * VX_RUNS_CAP * (int)sizeof(u64)) != VX_OK) return VX_ERR_LAUNCH;
+        hipLaunchKernelGGL(vx_k_runs_split, dim3(B), dim3(1024), 0, st, pa, w.runs, ep);
+        int bwgs = B * ((capacity + VX_RUNS_BUCKET - 1) / VX_RUNS_BUCKET);      // buckets the call can have at most
+        if (bwgs > B * VX_RUNS_MAXB) bwgs = B * VX_RUNS_MAXB;
+        if (bwgs > 1024) bwgs = 1024;
+        hipLaunchKernelGGL(vx_k_runs_bucket, dim3(bwgs), dim3(512), 2 * VX_RUNS_CAP * sizeof(u64), st, pa, w.runs, ep);
     }
     vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
