@@ -46,6 +46,8 @@ if boff:
     cw = ws[boff:boff + 256].view(torch.int32).cpu().tolist()
     print("bitmask path: segments %d, work items %d; debug [items, tile pairs, visits, trips, hit boxes, edges] = %s"
           % (cw[0], cw[1], cw[8:14]))
+    st5 = cw[16:21]
+    print("runs_bucket stamps (ticks between phases: tables, gather, merge rounds, rows):", [st5[i + 1] - st5[i] for i in range(4)])
 off = lib.vx_batched_nms_stamps_offset(B, K)
 SW = 136
 allw = ws[off:off + B * SW * 8].view(torch.int64).view(B, SW).cpu().double()

@@ -1527,10 +1527,13 @@ __global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
 //                     bucket beyond the LDS buffer (possible with hundreds of classes and a long tail of ties in the
 //                     sample) is ranked key by key with binary searches over the other runs' pieces instead: slow, exact.
 // Keys are unique (the index is part of the key), so the order is total and the result equals the full sort's.
-#define VX_RUNS_BUCKET 2048            // keys per bucket aimed at
-#define VX_RUNS_MAXB 64                // buckets per image at most (more keys: larger buckets)
-#define VX_RUNS_PER_THREAD 8           // positions of a bucket per thread of vx_k_runs_bucket (512 threads)
-#define VX_RUNS_CAP (512 * VX_RUNS_PER_THREAD)   // keys a bucket merges in LDS (two buffers)
+#define VX_RUNS_BUCKET 1024            // keys per bucket aimed at
+#define VX_RUNS_MAXB 256               // buckets per image at most (more keys: larger buckets)
+#define VX_RUNS_THREADS 1024           // workgroup of vx_k_runs_bucket: about one key per thread -- a bucket is a chain of
+                                       // latencies (six dependent global loads, then per merge round ~12 dependent LDS reads
+                                       // per key), so keys per thread multiply its duration (8 per thread: 0.09 ms)
+#define VX_RUNS_PER_THREAD 2           // positions of a bucket per thread of vx_k_runs_bucket
+#define VX_RUNS_CAP (VX_RUNS_THREADS * VX_RUNS_PER_THREAD)   // keys a bucket merges in LDS (two buffers)
 #define VX_RUNS_SAMPLES 2048           // LDS sort size of the sample
 
 struct vx_runs_ws {
@@ -1591,8 +1594,11 @@ __global__ __launch_bounds__(1024) void vx_k_runs_split(vx_part_args a, vx_runs_
     }
     int nb = (total + VX_RUNS_BUCKET - 1) / VX_RUNS_BUCKET;
     nb = min(nb, VX_RUNS_MAXB);
-    // sample: the middle key of every block of `stride` keys of every run (the last block may be short): a sample stands for
-    // the keys around it -- sampling block ENDS left the tails of all runs, n_classes * stride / 2 keys, to the last bucket
+    // sample: one key of every block of `stride` keys of every run (the last block may be short), at an offset that differs
+    // from run to run (run c: c * stride / n_classes).  With ONE offset for all runs the samples of equally distributed
+    // runs come in clumps of n_classes nearly equal keys and the buckets alternate between tiny and three times the aim
+    // (simulated: 82 .. 3085 keys for 80 runs of ~700; staggered: 55 .. 1620); sampling block ends also left every run's
+    // tail to the last bucket
     const int stride = max(16, (total + 1023) / 1024);
     if (threadIdx.x < 64) {
         int v[4], tot = 0;
@@ -1614,7 +1620,7 @@ __global__ __launch_bounds__(1024) void vx_k_runs_split(vx_part_args a, vx_runs_
         if (i < nsamp) {
             int lo = 0, hi = NC;                     // run of sample i: s_soff[lo] <= i < s_soff[hi]
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_soff[mid] <= i) lo = mid; else hi = mid; }
-            key = k2[s_R[lo] + min((i - s_soff[lo]) * stride + (stride >> 1), s_len[lo] - 1)];
+            key = k2[s_R[lo] + min((i - s_soff[lo]) * stride + (lo * stride) / NC, s_len[lo] - 1)];
         }
         sk[i] = key;
     }
@@ -1641,7 +1647,7 @@ __global__ __launch_bounds__(1024) void vx_k_runs_split(vx_part_args a, vx_runs_
     }
 }
 
-__global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_ws rw, vx_epi_params ep) {
+__global__ __launch_bounds__(VX_RUNS_THREADS) void vx_k_runs_bucket(vx_part_args a, vx_runs_ws rw, vx_epi_params ep) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];         // [2 * VX_RUNS_CAP]
     __shared__ int s_R[VX_PART_MAX_CLASSES], s_lo[VX_PART_MAX_CLASSES], s_hi[VX_PART_MAX_CLASSES], s_off[VX_PART_MAX_CLASSES + 1];
     const int nt = blockDim.x, lane = vx_lane();
@@ -1649,7 +1655,13 @@ __global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_
     const int NC = a.p.n_classes;
     // the call's buckets are dealt round-robin to a bounded grid (a grid over every possible bucket of every image is
     // mostly workgroups that leave at once, and with 64 KiB of LDS each they queue behind one another)
+#ifdef VX_BM_DEBUG
+#define VX_RB_STAMP(k) do { if (wi == 5 && threadIdx.x == 0) rw.nlist[14 + (k)] = (int)clock64(); } while (0)
+#else
+#define VX_RB_STAMP(k)
+#endif
     for (int wi = blockIdx.x; wi < nlist; wi += gridDim.x) {
+    VX_RB_STAMP(0);
     const int ent = rw.list[wi];
     const int b = ent >> 8, j = ent & 255;
     const int nb = rw.nb[b];
@@ -1685,6 +1697,7 @@ __global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_
         if (lane == 63) s_off[NC] = incl;
     }
     __syncthreads();
+    VX_RB_STAMP(1);
     auto piece_of = [&](int i) __attribute__((always_inline)) -> int {      // s_off[c] <= i < s_off[c + 1] (empty pieces skipped)
         int lo = 0, hi = NC;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
@@ -1714,6 +1727,7 @@ __global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_
             if (o < cnt) { const int c = piece_of(o); rr[k] = c; src[o] = k2[s_R[c] + s_lo[c] + (o - s_off[c])]; }
         }
         __syncthreads();
+        VX_RB_STAMP(2);
         for (int lg = 0; (1 << lg) < NC; ++lg) {
 #pragma unroll
             for (int k = 0; k < VX_RUNS_PER_THREAD; ++k) {
@@ -1732,8 +1746,11 @@ __global__ __launch_bounds__(512) void vx_k_runs_bucket(vx_part_args a, vx_runs_
             __syncthreads();
             u64 *t = src; src = dst; dst = t;
         }
+        VX_RB_STAMP(3);
         const int rows = min(cnt, nk - o0);
         for (int i = threadIdx.x; i < rows; i += nt) write_row(o0 + i, src[i]);
+        __syncthreads();
+        VX_RB_STAMP(4);
     } else {
         // beyond the LDS buffer: the place of a key = the keys below it in every run's piece
         for (int i = threadIdx.x; i < cnt; i += nt) {
@@ -2684,8 +2701,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         hipLaunchKernelGGL(vx_k_runs_split, dim3(B), dim3(1024), 0, st, pa, w.runs, ep);
         int bwgs = B * ((capacity + VX_RUNS_BUCKET - 1) / VX_RUNS_BUCKET);      // buckets the call can have at most
         if (bwgs > B * VX_RUNS_MAXB) bwgs = B * VX_RUNS_MAXB;
-        if (bwgs > 1024) bwgs = 1024;
-        hipLaunchKernelGGL(vx_k_runs_bucket, dim3(bwgs), dim3(512), 2 * VX_RUNS_CAP * sizeof(u64), st, pa, w.runs, ep);
+        if (bwgs > 2048) bwgs = 2048;
+        hipLaunchKernelGGL(vx_k_runs_bucket, dim3(bwgs), dim3(VX_RUNS_THREADS), 2 * VX_RUNS_CAP * sizeof(u64), st, pa, w.runs, ep);
     }
     vx_prof_end(VX_PROF_SORT2, st);
     if (rc != VX_OK) return rc;
