@@ -1487,8 +1487,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_swe
 // Bitmask path, last step on the class-partitioned route: the registered segments are dealt round-robin to the
 // workgroups; each is resolved from its edge list (the chain sweep when the list overflowed) and its kept keys are
 // emitted exactly as vx_k_part_sweep would have done.
+#define VX_BM_SCAN_LDS_EDGES 4096       // sorted edges vx_k_bm_scan keeps in LDS (16 KiB >= the chain sweep's ring for 4 waves)
 __global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
-    extern __shared__ __attribute__((aligned(16))) u64 sk[];             // ring of the chain sweep (fallback only)
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];             // sorted edges / ring of the chain sweep (fallback)
     __shared__ union { vx_async_smem as; vx_bm_scan_smem sc; } U;
     const vx_nms_params &p = a.p;
     const int nsegs = min(a.bm.counters[0], a.bm.max_segs);
@@ -1503,7 +1504,7 @@ __global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
         int *c2 = a.count2 + b;
         int *kc = a.ordered ? a.hist + b * VX_PART_MAX_CLASSES + c : nullptr;
         if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
-                       sg.len * VX_BM_ECAP, sg.len, p.top_k)) {
+                       sg.len * VX_BM_ECAP, sg.len, p.top_k, reinterpret_cast<unsigned *>(sk), VX_BM_SCAN_LDS_EDGES)) {
             vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, k2, c2, kc);
         } else {
             vx_sweep_async(U.as, sk, a.sbox + region, sg.len, T, p.top_k, a.iou_count);
@@ -2402,7 +2403,7 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
         const long long region = ob + sg.lo;
         const u64 *kseg = a.keys1 + region;
         if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
-                       sg.len * VX_BM_ECAP, sg.len, p.top_k)) {
+                       sg.len * VX_BM_ECAP, sg.len, p.top_k, reinterpret_cast<unsigned *>(sk), (int)(a.lds_bytes / sizeof(unsigned)))) {
             vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, a.keys2 + region, nullptr, segk + sg.id);
         } else {
             vx_sweep_async(U.as, sk, a.sbox + region, sg.len, T, p.top_k, a.iou_count);
@@ -2611,7 +2612,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         hipLaunchKernelGGL(vx_k_bm_finish, dim3(B), dim3(ia_threads), ia_lds, st, ia);
         if (part) {
             int sg = w.bm.max_segs < 4096 ? w.bm.max_segs : 4096;
-            hipLaunchKernelGGL(vx_k_bm_scan, dim3(sg), dim3(256), vx_async_ring_bytes(4), st, *part);
+            hipLaunchKernelGGL(vx_k_bm_scan, dim3(sg), dim3(256), VX_BM_SCAN_LDS_EDGES * sizeof(unsigned), st, *part);
         }
         vx_prof_end(VX_PROF_BM_SCAN, st);
         return VX_OK;

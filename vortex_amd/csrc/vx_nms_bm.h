@@ -449,14 +449,17 @@ struct vx_bm_scan_smem {
 
 // Whole workgroup.  edges[0..ecount) of a segment of n boxes -> kept masks in S.kept[0..S.ndone) (cut to the first top_k
 // kept boxes when top_k > 0).  Returns false (nothing done) when the edge list overflowed.  Ends synchronised.
-__device__ __noinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *__restrict__ edges2,
-                                        int ecount, int ecap, int n, int top_k) {
+// lds_e / lds_cap: LDS room for the sorted edges (used when they fit: the chain then reads LDS instead of waiting for a
+// global load per score tile -- RetinaFace b128: vx_k_bm_finish 0.108 -> see DESIGN; edges2 in global memory otherwise).
+__device__ __noinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *edges2_global,
+                                        int ecount, int ecap, int n, int top_k, unsigned *lds_e, int lds_cap) {
     const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nt = blockDim.x;
     n = __builtin_amdgcn_readfirstlane(n);
     ecount = __builtin_amdgcn_readfirstlane(ecount);
     if (ecount > ecap) return false;
     const int NT = (n + 63) >> 6, E = ecount;
+    unsigned *edges2 = E <= lds_cap ? lds_e : edges2_global;
     __syncthreads();
     for (int i = threadIdx.x; i < NT; i += nt) { S.cur[i] = 0; S.dead[i] = 0ull; }
     __syncthreads();
