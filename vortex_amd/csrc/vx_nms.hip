@@ -2200,11 +2200,26 @@ __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int
     const int D = p.D;
     for (int i = threadIdx.x; i < nk; i += nt)
         a.keep_idx[(long long)b * p.out_cap + i] = (long long)(sk[i] & 0xFFFFFFFFull);
-    // row gather: consecutive threads copy consecutive floats of the output
-    for (int e = threadIdx.x; e < nk * D; e += nt) {
-        int i = e / D, q = e - i * D;
-        int idx = (int)(sk[i] & 0xFFFFFFFFull);
-        a.out_det[((long long)b * p.out_cap + i) * D + q] = a.det[(ib + idx) * D + q];
+    // row gather: consecutive threads copy consecutive floats of the output; four gathers in flight per thread (one at a
+    // time, a 1 855-row x 16-float result was a chain of 29 dependent global loads per thread)
+    const int tot = nk * D;
+    for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * nt) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nt;
+            if (e < tot) {
+                const int i = e / D, q = e - i * D;
+                const int idx = (int)(sk[i] & 0xFFFFFFFFull);
+                v[u] = a.det[(ib + idx) * D + q];
+            }
+        }
+        float *dst = a.out_det + (long long)b * p.out_cap * D;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nt;
+            if (e < tot) dst[e] = v[u];
+        }
     }
     __syncthreads();
     VX_STAMP(7);
@@ -2397,6 +2412,8 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
     const vx_thr T = vx_make_thr(p.thr);
     int *segk = a.segk + (long long)b * VX_MAX_CLASSES;
     if (threadIdx.x == 0) s_count2 = 0;
+#define VX_FSTAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + 8 + (k)] = clock64(); } while (0)
+    VX_FSTAMP(0);
     for (int q = 0; q < nexp; ++q) {
         const int si = a.bm.img_exp[b * VX_BM_MAXEXP + q];
         const vx_bm_seg sg = a.bm.segs[si];
@@ -2404,6 +2421,7 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
         const u64 *kseg = a.keys1 + region;
         if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
                        sg.len * VX_BM_ECAP, sg.len, p.top_k, reinterpret_cast<unsigned *>(sk), (int)(a.lds_bytes / sizeof(unsigned)))) {
+            VX_FSTAMP(1);
             vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, a.keys2 + region, nullptr, segk + sg.id);
         } else {
             vx_sweep_async(U.as, sk, a.sbox + region, sg.len, T, p.top_k, a.iou_count);
@@ -2411,7 +2429,10 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
         }
     }
     __syncthreads();
+    VX_FSTAMP(2);
     vx_image_tail(a, b, n, nseg, true, sk, s_gcnt, &s_count2, 0, 0);
+    VX_FSTAMP(3);
+#undef VX_FSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------

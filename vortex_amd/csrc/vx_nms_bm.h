@@ -106,7 +106,7 @@ __device__ __forceinline__ void vx_bm_block_scan(int *h, int cnt, int *wtot) {
 // Whole workgroup.  sbox = the segment's class-offset boxes in score order (global, written by this workgroup before a
 // barrier).  scratch = VX_BM_PREP_SCRATCH(n) bytes of LDS (4-byte aligned).  Returns false (nothing registered) when a box
 // is not tame.  region = b * npad_cap + lo.
-__device__ __noinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, const vx_bm_ws w, int b, int lo, int id, int route,
+__device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, const vx_bm_ws w, int b, int lo, int id, int route,
                                         const vx_f4 *__restrict__ sbox, int n) {
     const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W = blockDim.x >> 6, nt = blockDim.x;
@@ -447,11 +447,101 @@ struct vx_bm_scan_smem {
     int ndone;
 };
 
+// The chain of vx_bm_scan (one wave): walks the score tiles in order over the edges sorted by suppressor tile.
+// LDS_E: the sorted edges are in LDS (reads through the LDS address space: a generic pointer would make every read a
+// flat load, 4x the latency of a ds_read on this serial path).
+typedef __attribute__((address_space(3))) unsigned vx_lds_u32;
+template <bool LDS_E>
+__device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *edges2, int n, int NT, int top_k) {
+    const int lane = vx_lane();
+    auto ld = [&](int k) __attribute__((always_inline)) -> unsigned {
+        if (LDS_E) return ((const vx_lds_u32 *)edges2)[k];
+        return edges2[k];
+    };
+    // The tile's edges live in registers (4 per lane; a tile with more than 256 edges reads the rest from memory)
+    // and the next tile's are requested before this tile is resolved: the chain never waits for a cold load.
+    constexpr unsigned NONE = 0xFFFFFFFFu;         // lo = hi = 65535: matches no tile
+    auto load4 = [&](int t, unsigned *e) __attribute__((always_inline)) {
+        const int s0 = t < NT ? S.start[t] : 0, s1 = t < NT ? S.start[t + 1] : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = s0 + q * 64 + lane; e[q] = k < s1 ? ld(k) : NONE; }
+    };
+    unsigned ec[4], en[4];
+    load4(0, ec);
+    int ktot = 0, ndone = NT;
+    for (int t = 0; t < NT; ++t) {
+        load4(t + 1, en);
+        const int s0 = S.start[t], s1 = S.start[t + 1];
+        const int rem = n - t * 64;
+        u64 alive = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & ~S.dead[t];
+        alive = vx_uniform64(alive);
+        if (s1 > s0 && alive) {
+            // the tile's own edges -> in-tile rows, resolved greedily by a bit walk over the boxes that suppress somebody
+            S.rows[lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
+                if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
+            }
+            for (int k = s0 + 256 + lane; k < s1; k += 64) {
+                const unsigned e = ld(k);
+                const unsigned lo = e >> 16, hi = e & 0xFFFFu;
+                if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
+            }
+            if (__ballot(any)) {
+                __builtin_amdgcn_wave_barrier();
+                const u64 row = S.rows[lane];
+                const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
+                const u64 has = __ballot(row != 0ull);
+                u64 todo = alive & has;
+                while (todo) {
+                    const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                    const u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
+                                   (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
+                    alive &= ~mi;
+                    todo = alive & has & ~((2ull << i) - 1ull);
+                }
+            }
+        }
+        int nk = __popcll(alive);
+        bool stop = false;
+        if (top_k > 0 && ktot + nk >= top_k) {       // only the segment's first top_k kept boxes matter
+            int excess = ktot + nk - top_k;
+            while (excess-- > 0) alive &= ~(1ull << (63 - __builtin_clzll(alive)));
+            nk = top_k - ktot;
+            stop = true;
+        }
+        ktot += nk;
+        if (lane == 0) S.kept[t] = alive;
+        if (stop) { ndone = t + 1; break; }
+        if (alive && s1 > s0) {                      // edges of the kept boxes: their targets in later tiles die
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
+                if (ec[q] != NONE && ((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
+                    atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
+            }
+            for (int k = s0 + 256 + lane; k < s1; k += 64) {
+                const unsigned e = ld(k);
+                const unsigned lo = e >> 16, hi = e & 0xFFFFu;
+                if (((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
+                    atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ec[q] = en[q];
+    }
+    if (lane == 0) S.ndone = ndone;
+}
+
 // Whole workgroup.  edges[0..ecount) of a segment of n boxes -> kept masks in S.kept[0..S.ndone) (cut to the first top_k
 // kept boxes when top_k > 0).  Returns false (nothing done) when the edge list overflowed.  Ends synchronised.
 // lds_e / lds_cap: LDS room for the sorted edges (used when they fit: the chain then reads LDS instead of waiting for a
 // global load per score tile -- RetinaFace b128: vx_k_bm_finish 0.108 -> see DESIGN; edges2 in global memory otherwise).
-__device__ __noinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *edges2_global,
+__device__ __forceinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *edges2_global,
                                         int ecount, int ecap, int n, int top_k, unsigned *lds_e, int lds_cap) {
     const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nt = blockDim.x;
@@ -488,83 +578,8 @@ __device__ __noinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__re
     }
     __syncthreads();                                    // edges2 is visible to this workgroup
     if (wv == 0) {
-        // The tile's edges live in registers (4 per lane; a tile with more than 256 edges reads the rest from memory)
-        // and the next tile's are requested before this tile is resolved: the chain never waits for a cold load.
-        constexpr unsigned NONE = 0xFFFFFFFFu;         // lo = hi = 65535: matches no tile
-        auto load4 = [&](int t, unsigned *e) __attribute__((always_inline)) {
-            const int s0 = t < NT ? S.start[t] : 0, s1 = t < NT ? S.start[t + 1] : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int k = s0 + q * 64 + lane; e[q] = k < s1 ? edges2[k] : NONE; }
-        };
-        unsigned ec[4], en[4];
-        load4(0, ec);
-        int ktot = 0, ndone = NT;
-        for (int t = 0; t < NT; ++t) {
-            load4(t + 1, en);
-            const int s0 = S.start[t], s1 = S.start[t + 1];
-            const int rem = n - t * 64;
-            u64 alive = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & ~S.dead[t];
-            alive = vx_uniform64(alive);
-            if (s1 > s0 && alive) {
-                // the tile's own edges -> in-tile rows, resolved greedily by a bit walk over the boxes that suppress somebody
-                S.rows[lane] = 0ull;
-                __builtin_amdgcn_wave_barrier();
-                bool any = false;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
-                    if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
-                }
-                for (int k = s0 + 256 + lane; k < s1; k += 64) {
-                    const unsigned e = edges2[k];
-                    const unsigned lo = e >> 16, hi = e & 0xFFFFu;
-                    if ((int)(hi >> 6) == t) { atomicOr((unsigned long long *)&S.rows[lo & 63u], 1ull << (hi & 63u)); any = true; }
-                }
-                if (__ballot(any)) {
-                    __builtin_amdgcn_wave_barrier();
-                    const u64 row = S.rows[lane];
-                    const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
-                    const u64 has = __ballot(row != 0ull);
-                    u64 todo = alive & has;
-                    while (todo) {
-                        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-                        const u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) |
-                                       (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
-                        alive &= ~mi;
-                        todo = alive & has & ~((2ull << i) - 1ull);
-                    }
-                }
-            }
-            int nk = __popcll(alive);
-            bool stop = false;
-            if (top_k > 0 && ktot + nk >= top_k) {       // only the segment's first top_k kept boxes matter
-                int excess = ktot + nk - top_k;
-                while (excess-- > 0) alive &= ~(1ull << (63 - __builtin_clzll(alive)));
-                nk = top_k - ktot;
-                stop = true;
-            }
-            ktot += nk;
-            if (lane == 0) S.kept[t] = alive;
-            if (stop) { ndone = t + 1; break; }
-            if (alive && s1 > s0) {                      // edges of the kept boxes: their targets in later tiles die
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned lo = ec[q] >> 16, hi = ec[q] & 0xFFFFu;
-                    if (ec[q] != NONE && ((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
-                        atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
-                }
-                for (int k = s0 + 256 + lane; k < s1; k += 64) {
-                    const unsigned e = edges2[k];
-                    const unsigned lo = e >> 16, hi = e & 0xFFFFu;
-                    if (((alive >> (lo & 63u)) & 1ull) && (int)(hi >> 6) > t)
-                        atomicOr((unsigned long long *)&S.dead[hi >> 6], 1ull << (hi & 63u));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ec[q] = en[q];
-        }
-        if (lane == 0) S.ndone = ndone;
+        if (E <= lds_cap) vx_bm_chain<true>(S, edges2, n, NT, top_k);
+        else vx_bm_chain<false>(S, edges2, n, NT, top_k);
     }
     __syncthreads();
     return true;
