@@ -57,6 +57,8 @@ print("per-wave cycles of the column-owner sweep, image 0: [wait, apply, chain, 
 for w_ in range(16):
     print("  wave %2d " % w_, [int(v) for v in wv[0, w_, :8]])
 print("mean over images and waves:", [int(v) for v in wv[:, :, :8].mean(dim=(0, 1))])
+ss = allw[:, 16:19]
+print("vx_bm_scan phases (mean ticks): edge sort %.0f  chain %.0f;  edges/image %s" % ((ss[:, 1] - ss[:, 0]).mean(), (ss[:, 2] - ss[:, 1]).mean(), ""))
 fs = allw[:, 8:12]
 print("vx_k_bm_finish phases (mean ticks): scan %.0f  emit %.0f  tail %.0f" % tuple((fs[:, i + 1] - fs[:, i]).mean() for i in range(3)))
 d = (st[:, 1:] - st[:, :-1])

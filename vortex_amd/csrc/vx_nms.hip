@@ -2420,7 +2420,8 @@ __global__ __launch_bounds__(1024) void vx_k_bm_finish(vx_image_args a) {
         const long long region = ob + sg.lo;
         const u64 *kseg = a.keys1 + region;
         if (vx_bm_scan(U.sc, a.bm.edges + region * VX_BM_ECAP, a.bm.edges2 + region * VX_BM_ECAP, a.bm.ecount[si],
-                       sg.len * VX_BM_ECAP, sg.len, p.top_k, reinterpret_cast<unsigned *>(sk), (int)(a.lds_bytes / sizeof(unsigned)))) {
+                       sg.len * VX_BM_ECAP, sg.len, p.top_k, reinterpret_cast<unsigned *>(sk), (int)(a.lds_bytes / sizeof(unsigned)),
+                       a.stamps ? a.stamps + b * VX_STAMP_WORDS + 16 : nullptr)) {
             VX_FSTAMP(1);
             vx_masks_emit(U.sc.kept, U.sc.ndone, kseg, a.keys2 + region, nullptr, segk + sg.id);
         } else {

@@ -542,7 +542,7 @@ __device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *
 // lds_e / lds_cap: LDS room for the sorted edges (used when they fit: the chain then reads LDS instead of waiting for a
 // global load per score tile -- RetinaFace b128: vx_k_bm_finish 0.108 -> see DESIGN; edges2 in global memory otherwise).
 __device__ __forceinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *__restrict__ edges, unsigned *edges2_global,
-                                        int ecount, int ecap, int n, int top_k, unsigned *lds_e, int lds_cap) {
+                                        int ecount, int ecap, int n, int top_k, unsigned *lds_e, int lds_cap, u64 *dbg = nullptr) {
     const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nt = blockDim.x;
     n = __builtin_amdgcn_readfirstlane(n);
@@ -550,7 +550,9 @@ __device__ __forceinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *_
     if (ecount > ecap) return false;
     const int NT = (n + 63) >> 6, E = ecount;
     unsigned *edges2 = E <= lds_cap ? lds_e : edges2_global;
+#define VX_SCAN_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
     __syncthreads();
+    VX_SCAN_STAMP(0);
     for (int i = threadIdx.x; i < NT; i += nt) { S.cur[i] = 0; S.dead[i] = 0ull; }
     __syncthreads();
     for (int k = threadIdx.x; k < E; k += nt) atomicAdd(&S.cur[edges[k] >> 22], 1);      // (lo rank >> 6) = bits 22..
@@ -577,10 +579,13 @@ __device__ __forceinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *_
         edges2[atomicAdd(&S.cur[e >> 22], 1)] = e;
     }
     __syncthreads();                                    // edges2 is visible to this workgroup
+    VX_SCAN_STAMP(1);
     if (wv == 0) {
         if (E <= lds_cap) vx_bm_chain<true>(S, edges2, n, NT, top_k);
         else vx_bm_chain<false>(S, edges2, n, NT, top_k);
     }
+    VX_SCAN_STAMP(2);
     __syncthreads();
+#undef VX_SCAN_STAMP
     return true;
 }
