@@ -402,7 +402,13 @@ def test_fused_candidates_vs_oracle_any_seed(seed, sthr):
 
 
 # ------------------------------------------------------------------------------------------- K4
-@pytest.mark.parametrize("L,NL,P,B,sthr", [(5, 2, 50400, 2, 0.5), (0, 21, 50400, 2, 0.3), (0, 21, 1000, 3, 0.0), (5, 2, 777, 1, 0.02)])
+@pytest.mark.parametrize("L,NL,P,B,sthr", [(5, 2, 50400, 2, 0.5), (0, 21, 50400, 2, 0.3), (0, 21, 1000, 3, 0.0), (5, 2, 777, 1, 0.02),
+                                            # rows of 2, 3, 4 16-byte chunks with the logits in the last one (scored from
+                                            # registers), each with the first logit at 0 and at 2; every row passing
+                                            (0, 4, 3001, 2, 0.3), (1, 2, 2049, 2, 0.4), (2, 4, 1500, 1, 0.0), (3, 2, 5000, 2, 0.6),
+                                            (4, 4, 1024, 3, 0.25), (5, 2, 4097, 2, 0.0),
+                                            # general kernel: even / odd row length, 8 and 16 loads per thread
+                                            (0, 2, 2500, 2, 0.5), (1, 3, 1300, 2, 0.2), (0, 40, 1100, 2, 0.1), (6, 9, 900, 1, 0.0)])
 def test_prior_decode_and_postprocess(L, NL, P, B, sthr):
     priors = O.make_priors(640) if P == 50400 else torch.rand(P, 4) * 0.5 + 0.1
     x = O.synth_prior_head(B, P, L, NL, seed=51)

@@ -7,8 +7,8 @@
 //          records form a spatial tile with a bounding box.  The segment is registered in a device-side list, one work
 //          item per spatial tile.
 //   pairs  vx_k_bm_pairs, a grid over ALL work items (segment, tile B): one wave holds tile B's 64 boxes in its
-//          lanes and visits the tiles A it owns a pair with (every unordered tile pair has one owner, chosen so
-//          that each tile owns about half of its pairs) whose bounding boxes meet; of tile A only the boxes that
+//          lanes and visits the tiles A it owns a pair with (every unordered tile pair has one owner: the tile
+//          with the smaller bounding box, ties to the lower index) whose bounding boxes meet; of tile A only the boxes that
 //          reach into B's bounding box are tested (four per trip, the cheap candidate test of the chain sweep, the
 //          exact predicate for lanes that fail it).  The reference's predicate is symmetric in the two boxes, so a
 //          hit is stored once, as the edge (lower rank -> higher rank): "if the first box is kept, the second is
