@@ -75,7 +75,10 @@ __host__ __device__ __forceinline__ int vx_bm_max_segs_per_image(int cap) { retu
 #define VX_BM_MAXSLAB 16              // slabs per size class: ceil(sqrt(256 tiles))
 #define VX_BM_NKEY2 (3 * VX_BM_MAXSLAB * VX_BM_YB)
 #define VX_BM_LEVELS_MIN 2048         // segments below this many boxes keep one size class
-#define VX_BM_PREP_SCRATCH(n) ((size_t)(3 * VX_BM_XB + 3 + VX_BM_NKEY2) * 4 + (size_t)(n) * 2)   // bytes of LDS scratch
+#define VX_BM_PREP_TBB(n) ((size_t)(((n) + 63) >> 6) * 16)                 // tile bounding boxes (ordered ints)
+#define VX_BM_PREP_KEY2(n) (((size_t)(n) * 2 + 15) & ~(size_t)15)
+#define VX_BM_PREP_SCRATCH(n) ((size_t)(3 * VX_BM_XB + 3 + VX_BM_NKEY2 + 1) * 4 + VX_BM_PREP_TBB(n) + VX_BM_PREP_KEY2(n))   // bytes of LDS scratch
+#define VX_BM_PREP_SCRATCH_BOXES(n) (VX_BM_PREP_SCRATCH(n) + (size_t)(n) * 16)   // ... with the LDS copy of the boxes
 
 struct vx_bm_prep_smem {
     int ext[4];
@@ -104,20 +107,25 @@ __device__ __forceinline__ void vx_bm_block_scan(int *h, int cnt, int *wtot) {
 }
 
 // Whole workgroup.  sbox = the segment's class-offset boxes in score order (global, written by this workgroup before a
-// barrier).  scratch = VX_BM_PREP_SCRATCH(n) bytes of LDS (4-byte aligned).  Returns false (nothing registered) when a box
-// is not tame.  region = b * npad_cap + lo.
-__device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, const vx_bm_ws w, int b, int lo, int id, int route,
-                                        const vx_f4 *__restrict__ sbox, int n) {
-    const int lane = vx_lane(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = blockDim.x >> 6, nt = blockDim.x;
+// barrier).  scratch = scratch_bytes >= VX_BM_PREP_SCRATCH(n) bytes of LDS (16-byte aligned); with
+// VX_BM_PREP_SCRATCH_BOXES(n) bytes the three passes read the boxes from an LDS copy instead of global memory (each
+// pass is a short loop of dependent load -> LDS atomic steps: the load's latency is most of it).  Returns false
+// (nothing registered) when a box is not tame.  region = b * npad_cap + lo.
+__device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, size_t scratch_bytes, const vx_bm_ws w, int b, int lo,
+                                        int id, int route, const vx_f4 *__restrict__ sbox, int n) {
+    const int lane = vx_lane(), nt = blockDim.x;
     n = __builtin_amdgcn_readfirstlane(n);
     const int NT = (n + 63) >> 6;
     const long long region = (long long)b * w.npad_cap + lo;
-    int *hx = reinterpret_cast<int *>(scratch);                      // [3 * XB + 3] x histogram -> cursors (per class one spare)
-    int *h2 = hx + 3 * VX_BM_XB + 3;                                 // [NKEY2] (class, slab, y bin) histogram -> cursors
-    unsigned short *key2 = reinterpret_cast<unsigned short *>(h2 + VX_BM_NKEY2);   // [n]
+    int *tb = reinterpret_cast<int *>(scratch);                      // [NT][4] tile bounding boxes as ordered ints
+    int *hx = tb + 4 * NT;                                           // [3 * XB + 3] x histogram -> cursors (per class one spare)
+    int *h2 = hx + 3 * VX_BM_XB + 3;                                 // [NKEY2 + 1] (class, slab, y bin) histogram -> cursors
+    unsigned short *key2 = reinterpret_cast<unsigned short *>(h2 + VX_BM_NKEY2 + 1);   // [n]
+    vx_f4 *lbox = scratch_bytes >= VX_BM_PREP_SCRATCH_BOXES(n)
+                      ? reinterpret_cast<vx_f4 *>(reinterpret_cast<char *>(scratch) + VX_BM_PREP_SCRATCH(n)) : nullptr;
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * VX_BM_XB + 3 + VX_BM_NKEY2; i += nt) hx[i] = 0;
+    for (int i = threadIdx.x; i < 4 * NT; i += nt) tb[i] = (i & 2) ? (int)0x80000000 : 0x7fffffff;
     if (threadIdx.x == 0) {
         S.ext[0] = S.ext[1] = 0x7fffffff; S.ext[2] = S.ext[3] = (int)0x80000000;
         S.untame = 0; S.fail = 0;
@@ -128,6 +136,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, co
         bool bad = false;
         for (int i = threadIdx.x; i < n; i += nt) {
             const vx_f4 q = sbox[i];
+            if (lbox) lbox[i] = q;
             bad |= !vx_tame(q, (q.z - q.x) * (q.w - q.y));
             const float cx = q.x + q.z, cy = q.y + q.w;
             mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx); mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
@@ -171,7 +180,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, co
     };
     // pass 1: histogram over (size class, x bin)
     for (int i = threadIdx.x; i < n; i += nt) {
-        const vx_f4 q = sbox[i];
+        const vx_f4 q = lbox ? lbox[i] : sbox[i];
         atomicAdd(&hx[level_of(q) * (VX_BM_XB + 1) + xbin_of(q)], 1);
     }
     __syncthreads();
@@ -191,7 +200,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, co
         per_l[L] = max(64, ((ntl + sl - 1) / sl) * 64);                    // boxes per slab (whole tiles)
     }
     for (int i = threadIdx.x; i < n; i += nt) {
-        const vx_f4 q = sbox[i];
+        const vx_f4 q = lbox ? lbox[i] : sbox[i];
         const int L = level_of(q);
         const int xr = atomicAdd(&hx[L * (VX_BM_XB + 1) + xbin_of(q)], 1) - S.lvl_start[L];
         const int slab = min(VX_BM_MAXSLAB - 1, xr / (L == 0 ? per_l[0] : (L == 1 ? per_l[1] : per_l[2])));
@@ -204,27 +213,22 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, co
     __syncthreads();
     vx_bm_block_scan<(VX_BM_NKEY2 + 255) / 256>(h2, VX_BM_NKEY2, S.wtot);      // 12 per thread covers 256-thread workgroups
     vx_bm_rec *recs = w.recs + region;
-    for (int i = threadIdx.x; i < n; i += nt) {         // pass 3: scatter (any order inside a bin)
-        const vx_f4 q = sbox[i];
+    for (int i = threadIdx.x; i < n; i += nt) {         // pass 3: scatter (any order inside a bin), tile bounding boxes
+        const vx_f4 q = lbox ? lbox[i] : sbox[i];
         const int pos = atomicAdd(&h2[key2[i]], 1);
         vx_bm_rec r;
         r.x1 = q.x; r.y1 = q.y; r.x2 = q.z; r.y2 = q.w; r.area = (q.z - q.x) * (q.w - q.y); r.rank = i; r.pad0 = 0; r.pad1 = 0;
         recs[pos] = r;
+        int *t4 = tb + 4 * (pos >> 6);
+        atomicMin(&t4[0], vx_f2ord(q.x)); atomicMin(&t4[1], vx_f2ord(q.y));
+        atomicMax(&t4[2], vx_f2ord(q.z)); atomicMax(&t4[3], vx_f2ord(q.w));
     }
-    __syncthreads();                                    // the records are visible to this workgroup
+    __syncthreads();
     const int ib = S.ib, si = S.si;
-    for (int v = wv; v < NT; v += W) {                  // bounding boxes of the spatial tiles
-        vx_f4 q = {3e38f, 3e38f, -3e38f, -3e38f};
-        if (v * 64 + lane < n) {
-            const vx_bm_rec r = recs[v * 64 + lane];
-            q.x = r.x1; q.y = r.y1; q.z = r.x2; q.w = r.y2;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            q.x = fminf(q.x, __shfl_xor(q.x, d)); q.y = fminf(q.y, __shfl_xor(q.y, d));
-            q.z = fmaxf(q.z, __shfl_xor(q.z, d)); q.w = fmaxf(q.w, __shfl_xor(q.w, d));
-        }
-        if (lane == 0) { w.tbb[ib + v] = q; w.item_seg[ib + v] = si; }
+    for (int v = threadIdx.x; v < NT; v += nt) {
+        vx_f4 q;
+        q.x = vx_ord2f(tb[4 * v]); q.y = vx_ord2f(tb[4 * v + 1]); q.z = vx_ord2f(tb[4 * v + 2]); q.w = vx_ord2f(tb[4 * v + 3]);
+        w.tbb[ib + v] = q; w.item_seg[ib + v] = si;
     }
     __syncthreads();
     return true;
