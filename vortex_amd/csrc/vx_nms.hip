@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_swe
 // Bitmask path, last step on the class-partitioned route: the registered segments are dealt round-robin to the
 // workgroups; each is resolved from its edge list (the chain sweep when the list overflowed) and its kept keys are
 // emitted exactly as vx_k_part_sweep would have done.
-#define VX_BM_SCAN_LDS_EDGES 4096       // sorted edges vx_k_bm_scan keeps in LDS (16 KiB >= the chain sweep's ring for 4 waves)
+#define VX_BM_SCAN_LDS_EDGES 4096       // words of LDS of vx_k_bm_scan: sorted edges + suppressor columns (16 KiB >= the chain sweep's ring for 4 waves)
 __global__ __launch_bounds__(256, 8) void vx_k_bm_scan(vx_part_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];             // sorted edges / ring of the chain sweep (fallback)
     __shared__ union { vx_async_smem as; vx_bm_scan_smem sc; } U;

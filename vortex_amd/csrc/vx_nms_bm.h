@@ -454,10 +454,18 @@ struct vx_bm_scan_smem {
 // The chain of vx_bm_scan (one wave): walks the score tiles in order over the edges sorted by suppressor tile.
 // LDS_E: the sorted edges are in LDS (reads through the LDS address space: a generic pointer would make every read a
 // flat load, 4x the latency of a ds_read on this serial path).
+// COLS (needs LDS_E): cols[t * 64 + i] = the boxes of score tile t that suppress box i of the same tile if kept, built
+// for all tiles at once by the whole workgroup before the chain starts.  The tile is then resolved in as many steps as
+// its longest suppression chain is deep (a box is decided once all its suppressors are: a handful of ballots) instead
+// of one scalar step per suppressing box, and the serial path per tile shrinks to: dead mask -> resolve -> dead-mask
+// atomics of the kept boxes' edges.
 typedef __attribute__((address_space(3))) unsigned vx_lds_u32;
-template <bool LDS_E>
-__device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *edges2, int n, int NT, int top_k) {
+typedef __attribute__((address_space(3))) u64 vx_lds_u64;
+template <bool LDS_E, bool COLS>
+__device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *edges2, const u64 *cols, int n, int NT, int top_k, u64 *dbg = nullptr) {
     const int lane = vx_lane();
+    u64 c_a = 0, c_b = 0, c_c = 0, c_d = 0, cs = dbg ? clock64() : 0;
+#define VX_CH_LAP(acc) do { if (dbg) { u64 now_ = clock64(); acc += now_ - cs; cs = now_; } } while (0)
     auto ld = [&](int k) __attribute__((always_inline)) -> unsigned {
         if (LDS_E) return ((const vx_lds_u32 *)edges2)[k];
         return edges2[k];
@@ -472,14 +480,30 @@ __device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *
     };
     unsigned ec[4], en[4];
     load4(0, ec);
+    u64 colc = COLS ? ((const vx_lds_u64 *)cols)[lane] : 0ull, coln = 0ull;
     int ktot = 0, ndone = NT;
     for (int t = 0; t < NT; ++t) {
         load4(t + 1, en);
+        if (COLS && t + 1 < NT) coln = ((const vx_lds_u64 *)cols)[(t + 1) * 64 + lane];
         const int s0 = S.start[t], s1 = S.start[t + 1];
         const int rem = n - t * 64;
         u64 alive = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & ~S.dead[t];
         alive = vx_uniform64(alive);
-        if (s1 > s0 && alive) {
+        VX_CH_LAP(c_a);
+        if (COLS) {
+            const u64 col = colc & alive;                  // suppressors that are dead already do not count
+            if (__ballot(col != 0ull) != 0ull) {
+                u64 kept = 0ull, und = alive;
+                while (und) {
+                    const bool ready = ((und >> lane) & 1ull) && (col & und) == 0ull;
+                    const bool k = ready && (col & kept) == 0ull;
+                    const u64 rm = vx_uniform64(__ballot(ready));
+                    kept |= vx_uniform64(__ballot(k));
+                    und &= ~rm;
+                }
+                alive = kept;
+            }
+        } else if (s1 > s0 && alive) {
             // the tile's own edges -> in-tile rows, resolved greedily by a bit walk over the boxes that suppress somebody
             S.rows[lane] = 0ull;
             __builtin_amdgcn_wave_barrier();
@@ -509,6 +533,7 @@ __device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *
                 }
             }
         }
+        VX_CH_LAP(c_b);
         int nk = __popcll(alive);
         bool stop = false;
         if (top_k > 0 && ktot + nk >= top_k) {       // only the segment's first top_k kept boxes matter
@@ -520,6 +545,7 @@ __device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *
         ktot += nk;
         if (lane == 0) S.kept[t] = alive;
         if (stop) { ndone = t + 1; break; }
+        VX_CH_LAP(c_c);
         if (alive && s1 > s0) {                      // edges of the kept boxes: their targets in later tiles die
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -537,7 +563,11 @@ __device__ __forceinline__ void vx_bm_chain(vx_bm_scan_smem &S, const unsigned *
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q) ec[q] = en[q];
+        colc = coln;
+        VX_CH_LAP(c_d);
     }
+    if (dbg && lane == 0) { dbg[3] = c_a; dbg[4] = c_b; dbg[5] = c_c; dbg[6] = c_d; }
+#undef VX_CH_LAP
     if (lane == 0) S.ndone = ndone;
 }
 
@@ -583,10 +613,24 @@ __device__ __forceinline__ bool vx_bm_scan(vx_bm_scan_smem &S, const unsigned *_
         edges2[atomicAdd(&S.cur[e >> 22], 1)] = e;
     }
     __syncthreads();                                    // edges2 is visible to this workgroup
+    // in-tile suppressor columns of all tiles, behind the sorted edges, when the LDS has the room
+    const int c0 = (E + 1) & ~1;
+    u64 *cols = (E <= lds_cap && c0 + NT * 128 <= lds_cap) ? reinterpret_cast<u64 *>(lds_e + c0) : nullptr;
+    if (cols) {
+        for (int i = threadIdx.x; i < NT * 64; i += nt) cols[i] = 0ull;
+        __syncthreads();
+        for (int k = threadIdx.x; k < E; k += nt) {
+            const unsigned e = edges2[k];
+            const unsigned lo = e >> 16, hi = e & 0xFFFFu;
+            if ((lo >> 6) == (hi >> 6)) atomicOr((unsigned long long *)&cols[hi], 1ull << (lo & 63u));
+        }
+        __syncthreads();
+    }
     VX_SCAN_STAMP(1);
     if (wv == 0) {
-        if (E <= lds_cap) vx_bm_chain<true>(S, edges2, n, NT, top_k);
-        else vx_bm_chain<false>(S, edges2, n, NT, top_k);
+        if (cols) vx_bm_chain<true, true>(S, edges2, cols, n, NT, top_k, dbg);
+        else if (E <= lds_cap) vx_bm_chain<true, false>(S, edges2, nullptr, n, NT, top_k);
+        else vx_bm_chain<false, false>(S, edges2, nullptr, n, NT, top_k);
     }
     VX_SCAN_STAMP(2);
     __syncthreads();
