@@ -269,6 +269,18 @@ int vx_yolo_fused_postprocess_overlapped(const float *d_head0, const float *d_he
                                          float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
                                          void *d_workspace, size_t workspace_bytes, void *stream, void *tail_stream);
 
+/* The per-batch step of a YOLOv3 predictor around the backbone in ONE host call: vx_preprocess_u8hwc_f32nchw
+ * (d_img u8[B,Hs,Ws,3] -> d_norm f32[B,3,S,S]: Normalize.forward, normalizer.py:74-77, with the stretch / letterbox
+ * resize of basic_runtime.py:66-90 when (Hs,Ws) != (S,S)) followed by vx_yolo_fused_postprocess on the three head
+ * tensors handed in (BasePredictor.forward, predictor/base_module.py:98-102, minus the network between the two).
+ * Arguments, outputs and return codes are those of the two calls; nothing is allocated or synchronised. */
+int vx_yolo_pipeline_step(const uint8_t *d_img, float *d_norm, int Hs, int Ws, const float mean[3],
+                          const float std[3], int scaler, int flip, int resize_mode, int pad_value,
+                          const float *d_head0, const float *d_head1, const float *d_head2, int B, int S, int C,
+                          const float anchors_px[18], float score_threshold, int use_threshold,
+                          float iou_threshold, int top_k, float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------- result formatting
  * vx_pack_rows + the output_format column slicing of get_prediction_results (predictor/utils.py:11-33) /
  * BaseRuntime.__call__ (src/runtime/vortex/runtime/basic_runtime.py:103-111) + the relative->absolute

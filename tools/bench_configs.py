@@ -272,8 +272,8 @@ def stress_cfg(steps=10, warmup=3, cpu_budget=8.0, top_k=300, tag="nms_stress_10
 
 def latency_cfg(steps=200, warmup=20, cpu_budget=4.0):
     """BASELINE configs[0] shape: YOLOv3 416x416, 80 classes, batch 1 -- the reference's own CPU-runnable case.  Reports
-    the synchronous latency of one image (pre-process + fused decode + NMS + result tuple) eagerly and as a HIP-graph
-    replay, beside the oracle's time for the same image on the host."""
+    the synchronous latency of one image (pre-process + fused decode + NMS + result tuple) eagerly (two module calls),
+    through the one-call step (vx_yolo_pipeline_step, buffers reused) and as a HIP-graph replay, beside the oracle's time for the same image on the host."""
     import bench
     import vortex_amd as V
     from vortex_amd.graphs import GraphedPostProcess
@@ -290,18 +290,25 @@ def latency_cfg(steps=200, warmup=20, cpu_budget=4.0):
             out = post(heads, st, it)
         return out
     graphed = GraphedPostProcess(post, heads, st, it, preprocess=norm, images=img)
+    one_call = V.YoloV3PipelineStep(norm, post)
+
+    def step(n):
+        for _ in range(n):
+            out = one_call(img, heads, st, it)[1]
+        return out
 
     def graph(n):
         for _ in range(n):
             out = graphed()
         return out
     rec = {"batch": 1, "thresholds": {"score": 0.9, "iou": 0.2}, "mode": "synchronous: every step returns its result tuple"}
-    for name, loop in (("eager", eager), ("hipgraph", graph)):
+    for name, loop in (("eager", eager), ("one_call", step), ("hipgraph", graph)):
         loop(warmup)
         sp = _spread(timed_repeats(loop, steps), steps)
         rec[name] = {"latency_ms": sp["median_ms_per_step"], "images_per_s": round(1e3 / sp["median_ms_per_step"], 1), "spread": sp}
-    rec["images_per_s"] = rec["eager"]["images_per_s"]
-    rec["ms_per_step"] = rec["eager"]["latency_ms"]
+    # the record's own figure: the one-call step (no graph capture needed); the two-module-call figure stays beside it
+    rec["images_per_s"] = rec["one_call"]["images_per_s"]
+    rec["ms_per_step"] = rec["one_call"]["latency_ms"]
     rec["detections_per_image"] = int(eager(1)[0].shape[0])
     del graphed
     if cpu_budget:

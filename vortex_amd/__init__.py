@@ -12,6 +12,7 @@ reference's own nn.Module API for that path:
     detr.DETRPostProcess
     runtime.resize_batch / format_detections / adjust_coordinates / InferenceHelper
     parallel.shard_batch / allgather_detections
+    YoloV3PipelineStep                   (pre-process + fused post-process in ONE library call: vx_yolo_pipeline_step)
     graphs.GraphedPostProcess            (HIP-graph replay for launch-bound batch sizes; import on demand)
     export                               (torch.library custom ops + ONNX symbolic; import on demand)
 """
@@ -24,5 +25,6 @@ from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostPro
 from .prior import PriorBoxDecoder, PriorBoxPostProcess  # noqa: F401
 from .detr import DETRPostProcess  # noqa: F401
 from .predictor import BasePredictor, create_predictor, get_prediction_results  # noqa: F401
+from .step import YoloV3PipelineStep  # noqa: F401
 
 __version__ = "0.1.0"

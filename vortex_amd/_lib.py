@@ -45,6 +45,9 @@ _SIGNATURES = {
     "vx_yolo_fused_postprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vx_yolo_fused_postprocess": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_float, c_int,
                                           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_yolo_pipeline_step": (c_int, [c_void_p, c_void_p, c_int, c_int, _F3, _F3, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_float, c_int,
+                                      c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vx_yolo_fused_postprocess_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_float,
                                                      c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_size_t, c_void_p, c_void_p]),

@@ -124,3 +124,20 @@ extern "C" int vx_yolo_fused_postprocess_overlapped(const float *d_head0, const 
     return vx_pipe_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, iou_threshold,
                         top_k, d_packed, d_meta, meta_mirror, d_workspace, workspace_bytes, stream, tail_stream);
 }
+
+// The whole per-batch step of a YOLOv3 predictor around the backbone, one host call: pre-process of THIS batch's
+// frames (d_img -> d_norm, the backbone's input) and post-process of the head tensors the caller hands in (normally
+// the backbone's output for the previous d_norm), chained on `stream`.  A synchronous batch-1 caller pays the host
+// side of a library call once instead of twice (marshalling + argument checks: ~5 us of a ~70 us step).
+// Same results as vx_preprocess_u8hwc_f32nchw followed by vx_yolo_fused_postprocess.
+extern "C" int vx_yolo_pipeline_step(const uint8_t *d_img, float *d_norm, int Hs, int Ws, const float mean[3],
+                                     const float std[3], int scaler, int flip, int resize_mode, int pad_value,
+                                     const float *d_head0, const float *d_head1, const float *d_head2, int B, int S, int C,
+                                     const float anchors_px[18], float score_threshold, int use_threshold,
+                                     float iou_threshold, int top_k, float *d_packed, int32_t *d_meta, int32_t *meta_mirror,
+                                     void *d_workspace, size_t workspace_bytes, void *stream) {
+    int rc = vx_preprocess_u8hwc_f32nchw(d_img, d_norm, B, Hs, Ws, S, S, mean, std, scaler, flip, resize_mode, pad_value, stream);
+    if (rc != VX_OK) return rc;
+    return vx_pipe_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, iou_threshold,
+                        top_k, d_packed, d_meta, meta_mirror, d_workspace, workspace_bytes, stream, stream);
+}
