@@ -31,7 +31,7 @@ struct vx_prior_params {
 //             row was streamed by this very workgroup a moment ago: L2 / Infinity Cache), decoded, and the four output
 //             tensors are written densely at base + i -- contiguous, coalesced stores.
 // Rounds 1-2 staged per-tile records and packed them in a second kernel (42-54 MB written and read back per batch).
-#define VX_PRIOR_TPW 4
+#define VX_PRIOR_TPW 2
 #define VX_PRIOR_TICKET_STRIDE 64     // ints between the ticket counters of two images: one 256-byte L2 channel line each
 
 typedef float vx_v4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -43,10 +43,10 @@ typedef float vx_v4u __attribute__((ext_vector_type(4), aligned(4)));
 #define VX_PRIOR_REG_NB 2             // batches per wave (A/B on the RetinaFace batch: 256x1 0.1125 ms, 128x2 0.108 ms)
 #endif
 #define VX_PRIOR_REG_GROUP (4 * VX_PRIOR_REG_RB * VX_PRIOR_REG_NB)
-#define VX_PRIOR_LIST (VX_PRIOR_REG_GROUP > VX_PRIOR_TPW * 256 ? VX_PRIOR_REG_GROUP : VX_PRIOR_TPW * 256)
 
+template <int LIST>
 struct vx_prior_smem {
-    int2 list[VX_PRIOR_LIST];
+    int2 list[LIST];
     int wcount[4];
     int grp, base;
 };
@@ -56,7 +56,10 @@ struct vx_prior_smem {
 // 24-64 bytes, and storing it from the lane costs one partial-line write request per lane and 8 bytes (measured: the
 // 53 MB of a RetinaFace batch took 25 us that way); the rows of a batch are contiguous in the output, so they go
 // through LDS and leave as whole 512-byte / 1-KB wave stores.
-__device__ __forceinline__ void vx_prior_emit(vx_prior_smem &S, float *__restrict__ stage, const vx_prior_params &p,
+// lloc (LDS, optional): the four box regressions of every listed survivor, kept by a caller that had the rows in LDS;
+// without it they are read again from the input (the row was streamed by this workgroup a moment ago).
+template <int LIST>
+__device__ __forceinline__ void vx_prior_emit(vx_prior_smem<LIST> &S, const vx_f4 *lloc, float *__restrict__ stage, const vx_prior_params &p,
                                               const float *__restrict__ img, const vx_f4 *__restrict__ priors,
                                               int *__restrict__ fl, int grp, int ngroups, int group_rows, int total,
                                               long long ob, float *__restrict__ boxes, float *__restrict__ scores,
@@ -80,7 +83,9 @@ __device__ __forceinline__ void vx_prior_emit(vx_prior_smem &S, float *__restric
             cid = e.x >> VX_PRIOR_ROWBITS;
             cf = __int_as_float(e.y);
             const float *srow = img + (long long)prow * NCOL;
-            const vx_v4u loc = *reinterpret_cast<const vx_v4u *>(srow);
+            vx_f4 loc;
+            if (lloc) loc = lloc[j];
+            else { const vx_v4u g4 = *reinterpret_cast<const vx_v4u *>(srow); loc.x = g4.x; loc.y = g4.y; loc.z = g4.z; loc.w = g4.w; }
             const vx_f4 pr = priors[prow];
             const float cx = pr.x + (loc.x * p.v0) * pr.z;
             const float cy = pr.y + (loc.y * p.v0) * pr.w;
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict
                                                          int *__restrict__ counts, int *__restrict__ status,
                                                          vx_prior_params p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    __shared__ vx_prior_smem S;
+    __shared__ vx_prior_smem<VX_PRIOR_TPW * 256> S;
+    __shared__ vx_f4 s_loc[VX_PRIOR_TPW * 256];                     // box regressions of the listed survivors
     const int groups = p.groups;
     const int b = blockIdx.x % p.B;                                 // neighbours in the grid draw from different counters
     if (threadIdx.x == 0) S.grp = atomicAdd(&tickets[b * VX_PRIOR_TICKET_STRIDE], 1);
@@ -267,12 +273,18 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode(const float *__restrict
         int base = wg_total;
         for (int w = 0; w < wave; ++w) base += S.wcount[w];
         // the survivor list: (row inside the group | class << 10, confidence) in row order
-        if (pass) S.list[base + vx_mbcnt(mk)] = make_int2(((t - t0) * 256 + r) | (ci << VX_PRIOR_ROWBITS), __float_as_int(conf));
+        if (pass) {
+            const int at = base + vx_mbcnt(mk);
+            S.list[at] = make_int2(((t - t0) * 256 + r) | (ci << VX_PRIOR_ROWBITS), __float_as_int(conf));
+            vx_f4 l4;
+            l4.x = row[0]; l4.y = row[1]; l4.z = row[2]; l4.w = row[3];
+            s_loc[at] = l4;
+        }
         wg_total += S.wcount[0] + S.wcount[1] + S.wcount[2] + S.wcount[3];
         __syncthreads();                                            // the tile and S.wcount are rewritten by the next trip
     }
     // (the tile is free: NCP >= 6 + 2L floats per row)
-    vx_prior_emit(S, tile, p, img, priors, flags + (long long)b * groups, grp, groups, VX_PRIOR_TPW * 256, wg_total, ob, boxes,
+    vx_prior_emit(S, s_loc, tile, p, img, priors, flags + (long long)b * groups, grp, groups, VX_PRIOR_TPW * 256, wg_total, ob, boxes,
                   scores, cls, det, counts + b);
     if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
 }
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode_reg(const float *__rest
                                                              int *__restrict__ counts, int *__restrict__ status,
                                                              vx_prior_params p) {
     constexpr int RB = VX_PRIOR_REG_RB, NB = VX_PRIOR_REG_NB, RPW = RB * NB;    // rows per wave: per batch, in all
-    __shared__ vx_prior_smem S;
+    __shared__ vx_prior_smem<VX_PRIOR_REG_GROUP> S;
     __shared__ union { int2 wlist[4][RPW]; float stage[256 * 4 * CPR]; } s_u;     // the wave lists, then the result rows
     const int groups = p.groups_reg;
     const int b = blockIdx.x % p.B;                                 // neighbours in the grid draw from different counters
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode_reg(const float *__rest
         S.list[j] = s_u.wlist[w][j - (w == 0 ? 0 : w == 1 ? c0 : w == 2 ? c1 : c2)];
     }
     __syncthreads();
-    vx_prior_emit(S, s_u.stage, p, img, priors, flags + (long long)b * groups, grp, groups, VX_PRIOR_REG_GROUP, total, ob, boxes,
+    vx_prior_emit(S, (const vx_f4 *)nullptr, s_u.stage, p, img, priors, flags + (long long)b * groups, grp, groups, VX_PRIOR_REG_GROUP, total, ob, boxes,
                   scores, cls, det, counts + b);
     if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
 }
