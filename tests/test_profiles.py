@@ -21,8 +21,8 @@ def test_traffic_file_covers_every_bench_record():
         assert value and src == os.path.relpath(files[-1], ROOT)
         k = newest[tag]["kernels"][kernel]
         assert value == k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
-    for tag, kernel in (("fpn_ssd_640_b64", "vx_k_prior_decode"), ("retinaface_640_b128", "vx_k_prior_decode"),
-                        ("yolo416_b256_dense", "vx_k_yolo_fused"), ("yolo416_b256_resize720p", "vx_k_resize_fast")):
+    for tag, kernel in (("fpn_ssd_640_b64", "vx_k_prior_decode"), ("retinaface_640_b128", "vx_k_prior_decode_reg"),
+                        ("yolo416_b256_dense", "vx_k_yolo_fused"), ("yolo416_b256_resize720p", "vx_k_resize_fast<true>")):
         assert tag in bench_configs.CONFIGS
         value, src = bench_configs._traffic(tag, kernel)
         assert value and value > 1e6, (tag, kernel)
@@ -38,7 +38,9 @@ def test_headline_traffic_is_close_to_the_algorithmic_bytes():
 
 
 def test_every_profile_has_its_bench_line_and_kernel_stats():
-    tags = {os.path.basename(f)[:-len("_kernel_stats.csv")] for f in glob.glob(os.path.join(ROOT, "profiles", "r02_*_kernel_stats.csv"))}
+    tags = {os.path.basename(f)[:-len("_kernel_stats.csv")] for f in glob.glob(os.path.join(ROOT, "profiles", "r0[23]_*_kernel_stats.csv"))}
     assert {"r02_default", "r02_dense", "r02_unfused", "r02_retinaface", "r02_fpn_ssd", "r02_stress", "r02_resize720p"} <= tags
+    assert {"r03_default", "r03_dense", "r03_unfused", "r03_retinaface", "r03_fpn_ssd", "r03_stress", "r03_stress_all",
+            "r03_resize720p", "r03_dense_cfg", "r03_b1"} <= tags
     for t in tags:
         assert os.path.exists(os.path.join(ROOT, "profiles", t + "_bench.json")), t

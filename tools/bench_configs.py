@@ -195,12 +195,17 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # single-class model whose images exceed 16384 candidates would lose that bet every time and switches it off
     pp.optimistic_nms = NL - 1 >= 4 or cand // B <= ops.NMS_SINGLE_LAUNCH_MAX
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
-    algo = B * P * NCOL * 4 + P * 16 + cand * (32 + 8 * Lm)         # rows + priors once + staged survivor records
+    # rows + priors once + the four output tensors (boxes 16, scores 4, labels 8, result rows 4 * (6 + 2L) bytes per
+    # candidate; the staged records of rounds 1-2 are gone)
+    algo = B * P * NCOL * 4 + P * 16 + cand * (52 + 8 * Lm)
+    # which of the two decode kernels ran (vx_prior_decode picks the register-scored one when a row's logits sit in
+    # its last 16-byte chunk)
+    in_regs = NCOL % 4 == 0 and 8 <= NCOL <= 16 and 4 + 2 * Lm >= NCOL - 4
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
            "batches_in_flight": 2, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
-           "roofline": _roof("vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
+           "roofline": _roof("vx_k_prior_decode_reg" if in_regs else "vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
     tests = _iou_tests(fn)
     rec["nms"] = _nms_record(tests, sum(kern.get(k, 0.0) for k in NMS_KERNELS))
     if cpu_budget:
