@@ -305,10 +305,11 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
     const u64 var = ((((u64)s_or[1]) << 32) | s_or[0]) >> 20 << 20;
     if (var == 0) return;                                           // one (class, score) for all: already in order
     const int b_lo = __ffsll((long long)var) - 1, b_hi = 63 - __clzll((long long)var);
+    for (int t = threadIdx.x; t < 256 * nw; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
     for (int shift = b_lo; shift <= b_hi; shift += 8) {
-        const unsigned mask = (1u << min(8, b_hi - shift + 1)) - 1u;
-        for (int t = threadIdx.x; t < 256 * nw; t += blockDim.x) hist[t] = 0;
-        __syncthreads();
+        const int nbits = min(8, b_hi - shift + 1);
+        const unsigned mask = (1u << nbits) - 1u;
         int dest[VX_RADIX_ROWS];                                    // counter index | rank << 16, until the scan is done
 #pragma unroll
         for (int r = 0; r < VX_RADIX_ROWS; ++r) {
@@ -318,9 +319,11 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
                 u64 peers = __ballot(valid);
 #pragma unroll
                 for (int bit = 0; bit < 8; ++bit) {
-                    const bool one = (d >> bit) & 1u;
-                    const u64 bm = __ballot(one);
-                    peers &= one ? bm : ~bm;
+                    if (bit < nbits) {
+                        const bool one = (d >> bit) & 1u;
+                        const u64 bm = __ballot(one);
+                        peers &= one ? bm : ~bm;
+                    }
                 }
                 const int below = vx_mbcnt(peers);
                 unsigned old = 0;
@@ -339,8 +342,11 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
             for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(incl, d); if (lane >= d) incl += y; }
             if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
-            unsigned run = incl - tot;
-            for (int w = 0; w < wave; ++w) run += s_wsum[w];
+            unsigned pre = lane < wave ? s_wsum[lane] : 0u;         // (wave < 16 <= 64 lanes)
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+            pre = __shfl(pre, 0);
+            const unsigned run = incl - tot + pre;
             uint4 o;
             o.x = run; o.y = run + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
             reinterpret_cast<uint4 *>(hist)[threadIdx.x] = o;
@@ -350,7 +356,8 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
         for (int r = 0; r < VX_RADIX_ROWS; ++r)
             if (r < rows && i0 + r * 64 < n) sk[hist[dest[r] & 0xFFFF] + (unsigned)(dest[r] >> 16)] = v[r];
         __syncthreads();
-        if (shift + 8 <= b_hi) {
+        if (shift + 8 <= b_hi) {                                    // next pass: keys in their new order, counters at zero
+            reinterpret_cast<uint4 *>(hist)[threadIdx.x] = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < VX_RADIX_ROWS; ++r) {
                 const int i = i0 + r * 64;
