@@ -219,8 +219,9 @@ int vx_batched_nms_small(const float *d_boxes, const float *d_scores, const int6
  * counterpart in the reference; it exists for callers that cannot allocate device memory -- code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  The workspace is a static device array of
  * vx_batched_nms_noalloc_max_bytes() = 64 MiB per GPU (held until the process ends); a call whose
- * vx_batched_nms_workspace_bytes(B, capacity) exceeds it returns VX_ERR_SCRATCH_LIMIT (e.g. B <= 110 at
- * capacity 10647, B <= 27 at capacity 50400).  The call itself performs no hipMalloc / hipFree; the first call
+ * vx_batched_nms_workspace_bytes(B, capacity) exceeds it returns VX_ERR_SCRATCH_LIMIT (e.g. B <= 106 at
+ * capacity 10647, B <= 14 at 22743, B <= 7 at 50400, B <= 3 at 100000: capacities above 16384 carry the edge
+ * lists and spatial records of the bitmask path).  The call itself performs no hipMalloc / hipFree; the first call
  * on a device looks the array's address up (make it outside graph capture).  All calls on one GPU share the
  * array: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
 size_t vx_batched_nms_noalloc_max_bytes(void);

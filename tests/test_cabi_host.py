@@ -68,7 +68,10 @@ def test_workspace_queries():
     assert lib.vx_yolo_fused_workspace_bytes(2, 416) >= 2 * 10647 * 32
     assert lib.vx_batched_nms_workspace_bytes(1, 2_000_000) == 0
     assert lib.vx_batched_nms_workspace_bytes(2, 10647) >= 2 * 16384 * 36
-    assert lib.vx_prior_decode_workspace_bytes(2, 50400, 5) >= 2 * 50400 * (32 + 40)
+    # round 3: no staged records any more, only the ticket counters (one 256-byte line per image) and one hand-off
+    # word per group of 512 rows
+    w = lib.vx_prior_decode_workspace_bytes(2, 50400, 5)
+    assert 2 * (64 + (50400 + 511) // 512) * 4 <= w < 4096
 
 
 def test_product_modules_refuse_cpu_tensors():
@@ -99,3 +102,17 @@ def test_reference_error_behaviour_on_host_checks():
     pp = V.YoloV3PostProcess(img_size=416)
     assert pp.additional_inputs == (('score_threshold', (1,)), ('iou_threshold', (1,)))
     assert len(pp.forward.__annotations__) and len(V.Normalize().forward.__annotations__)
+
+
+def test_documented_noalloc_batch_limits_match_the_library():
+    """include/vortex_hip.h and INTEGRATION.md quote the largest batch vx_batched_nms_noalloc accepts for a few
+    capacities; the workspace layout decides them (no GPU needed: both functions are host arithmetic)."""
+    from vortex_amd import _lib as L
+    lib = L.lib()
+    limit = lib.vx_batched_nms_noalloc_max_bytes()
+    assert limit == 64 << 20
+    for capacity, b_max in ((10647, 106), (22743, 14), (50400, 7), (100000, 3)):
+        assert lib.vx_batched_nms_workspace_bytes(b_max, capacity) <= limit, capacity
+        assert lib.vx_batched_nms_workspace_bytes(b_max + 1, capacity) > limit, capacity
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vortex_hip.h")).read()
+    assert "B <= 106" in text and "B <= 7 at 50400" in text
