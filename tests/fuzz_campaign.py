@@ -317,8 +317,46 @@ def declared_case(seed):
     return ok, dict(kind="declared", seed=seed, K=K, C=C, B=B, box=kind, thr=thr, top_k=top_k, optimistic=optimistic)
 
 
+def bitmask_case(seed):
+    """capacities beyond the single-launch kernel: whole-chip bitmask NMS of large class segments (image route and
+    class partition), its fall-backs, the score-prefix path of top_k and the optimistic call (tests/test_gpu_bitmask.py
+    with random shapes)."""
+    from tests.test_gpu_bitmask import make
+    g = torch.Generator().manual_seed(110_000 + seed)
+    K = int(torch.randint(16385, [24000, 52000, 100001][seed % 3], (1,), generator=g))
+    C = [1, 1, 3, 20, 80][seed % 5]
+    B = 1 + seed % 3
+    lo = [0.01, 0.02, 0.05, 0.2][(seed // 3) % 4]
+    wh = (lo, lo * [3, 10, 2][(seed // 5) % 3])
+    fill = [1.0, 0.4, 0.1][(seed // 2) % 3]                # image route needs <= 16384 candidates per image
+    n = [max(1, int(K * fill * float(torch.rand(1, generator=g)))) if (C <= 3 or b) else K for b in range(B)]
+    if C <= 3:
+        n = [min(v, 16000) for v in n]
+    kw = dict(dup=int(n[0] * 0.8) if seed % 11 == 0 else 0, untame=seed % 13 == 0, ties=[0, 0, 7, 1000][seed % 4],
+              pixel=seed % 6 == 0)
+    top_k = [None, None, 100, 300, 5000][(seed // 4) % 5]
+    thr = [0.45, 0.3, 0.6, 0.2][seed % 4]
+    optimistic = seed % 2 == 1
+    boxes, scores, cls, det, counts = make(B, K, C, seed=120_000 + seed, n=n, wh=wh, **kw)
+    d = [t.to(DEV) if t is not None else None for t in (boxes, scores, cls, det, counts)]
+    keep_idx, out_det, keep_counts, status = ops.batched_nms(*d, thr, C, top_k, optimistic=optimistic)
+    st = int(status.item())
+    if st & V._lib.VX_STATUS_DEFERRED:
+        keep_idx, out_det, keep_counts, status = ops.batched_nms(*d, thr, C, top_k)
+        st = int(status.item()) | (0 if optimistic else 1 << 30)      # a deferral without the optimistic flag is a failure
+    ok = ops.status_ok(st)
+    kc = keep_counts.cpu().tolist()
+    for b in range(B):
+        ref = O.batched_nms(boxes[b, :n[b]], scores[b, :n[b]], cls[b, :n[b]], torch.tensor([thr]))
+        if top_k:
+            ref = ref[:top_k]
+        ok = ok and kc[b] == ref.numel() and torch.equal(keep_idx[b, :kc[b]].cpu(), ref) \
+            and torch.equal(out_det[b, :kc[b]].cpu(), det[b][ref])
+    return ok, dict(kind="bitmask", seed=seed, K=K, C=C, B=B, n=n, wh=wh, thr=thr, top_k=top_k, optimistic=optimistic, **kw)
+
+
 CASES = (nms_case, ragged_case, yolo_case, prior_case, pre_case, layer_case, format_case, detr_case, nan_case,
-         nms_case, layer_case, declared_case, declared_case)
+         nms_case, layer_case, declared_case, declared_case, bitmask_case, bitmask_case)
 
 
 if __name__ == "__main__":

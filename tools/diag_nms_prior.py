@@ -60,6 +60,8 @@ print("mean over images and waves:", [int(v) for v in wv[:, :, :8].mean(dim=(0, 
 ss = allw[:, 16:19]
 print("vx_bm_scan phases (mean ticks): edge sort %.0f  chain %.0f;  edges/image %s" % ((ss[:, 1] - ss[:, 0]).mean(), (ss[:, 2] - ss[:, 1]).mean(), ""))
 print("vx_bm_chain sections (mean ticks): dead-mask wait %.0f  resolve %.0f  count/kept %.0f  cross edges + turn %.0f" % tuple(allw[:, 19:23].mean(0).tolist()))
+ps = allw[:, 24:32]
+print("vx_bm_prep phases (mean ticks): zero %.0f  extent+copy %.0f  x histogram %.0f  scan %.0f  slab pass %.0f  scan2 %.0f  scatter %.0f  tile boxes %.0f" % tuple([0.0] + [(ps[:, i + 1] - ps[:, i]).mean() for i in range(7)]))
 fs = allw[:, 8:12]
 print("vx_k_bm_finish phases (mean ticks): scan %.0f  emit %.0f  tail %.0f" % tuple((fs[:, i + 1] - fs[:, i]).mean() for i in range(3)))
 d = (st[:, 1:] - st[:, :-1])

@@ -2477,7 +2477,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         int *kc = merge ? segk + s_big[q][2] : nullptr;
         u64 *kd = merge ? k2 + lo : k2;
         if (bm_ok && len > VX_BM_MIN && len <= VX_BM_MAXN && VX_BM_PREP_SCRATCH(len) <= a.lds_bytes &&
-            vx_bm_prep(U.prep, sk, a.lds_bytes, a.bm, b, lo, s_big[q][2], 0, sb + lo, len)) {
+            vx_bm_prep(U.prep, sk, a.lds_bytes, a.bm, b, lo, s_big[q][2], 0, sb + lo, len, a.stamps ? (u64 *)(a.stamps + b * VX_STAMP_WORDS + 24) : nullptr)) {
             if (threadIdx.x == 0) { a.bm.img_exp[b * VX_BM_MAXEXP + s_nexp] = U.prep.si; ++s_nexp; }
             continue;
         }

@@ -99,8 +99,10 @@ __device__ __forceinline__ void vx_bm_block_scan(int *h, int cnt, int *wtot) {
     for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    int run = incl - tot;
-    for (int w2 = 0; w2 < wave && w2 < nw; ++w2) run += wtot[w2];
+    int pre = (lane < wave && lane < nw) ? wtot[lane] : 0;          // totals of the waves in front (<= 16), summed across lanes
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+    int run = incl - tot + __shfl(pre, 0);
 #pragma unroll
     for (int q = 0; q < PER; ++q) { const int k = threadIdx.x * PER + q; if (k < cnt) h[k] = run; run += v[q]; }
     __syncthreads();
@@ -112,7 +114,8 @@ __device__ __forceinline__ void vx_bm_block_scan(int *h, int cnt, int *wtot) {
 // pass is a short loop of dependent load -> LDS atomic steps: the load's latency is most of it).  Returns false
 // (nothing registered) when a box is not tame.  region = b * npad_cap + lo.
 __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, size_t scratch_bytes, const vx_bm_ws w, int b, int lo,
-                                        int id, int route, const vx_f4 *__restrict__ sbox, int n) {
+                                        int id, int route, const vx_f4 *__restrict__ sbox, int n, u64 *dbg = nullptr) {
+#define VX_PREP_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
     const int lane = vx_lane(), nt = blockDim.x;
     n = __builtin_amdgcn_readfirstlane(n);
     const int NT = (n + 63) >> 6;
@@ -124,6 +127,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
     vx_f4 *lbox = scratch_bytes >= VX_BM_PREP_SCRATCH_BOXES(n)
                       ? reinterpret_cast<vx_f4 *>(reinterpret_cast<char *>(scratch) + VX_BM_PREP_SCRATCH(n)) : nullptr;
     __syncthreads();
+    VX_PREP_STAMP(0);
     for (int i = threadIdx.x; i < 3 * VX_BM_XB + 3 + VX_BM_NKEY2; i += nt) hx[i] = 0;
     for (int i = threadIdx.x; i < 4 * NT; i += nt) tb[i] = (i & 2) ? (int)0x80000000 : 0x7fffffff;
     if (threadIdx.x == 0) {
@@ -134,12 +138,21 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
     {
         float mnx = 3e38f, mny = 3e38f, mxx = -3e38f, mxy = -3e38f;
         bool bad = false;
-        for (int i = threadIdx.x; i < n; i += nt) {
-            const vx_f4 q = sbox[i];
-            if (lbox) lbox[i] = q;
-            bad |= !vx_tame(q, (q.z - q.x) * (q.w - q.y));
-            const float cx = q.x + q.z, cy = q.y + q.w;
-            mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx); mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
+        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * nt) {             // four loads in flight per thread
+            vx_f4 q4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = i0 + k * nt; if (i < n) q4[k] = sbox[i]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nt;
+                if (i < n) {
+                    const vx_f4 q = q4[k];
+                    if (lbox) lbox[i] = q;
+                    bad |= !vx_tame(q, (q.z - q.x) * (q.w - q.y));
+                    const float cx = q.x + q.z, cy = q.y + q.w;
+                    mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx); mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
+                }
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -153,6 +166,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
         if (__ballot(bad) != 0ull && lane == 0) S.untame = 1;
     }
     __syncthreads();
+    VX_PREP_STAMP(1);
     if (S.untame) { __syncthreads(); return false; }
     if (threadIdx.x == 0) {
         const int si = atomicAdd(&w.counters[0], 1), ib = atomicAdd(&w.counters[1], NT);
@@ -184,12 +198,14 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
         atomicAdd(&hx[level_of(q) * (VX_BM_XB + 1) + xbin_of(q)], 1);
     }
     __syncthreads();
+    VX_PREP_STAMP(2);
     if (S.fail) { __syncthreads(); return false; }
     // exclusive scan of the 3 x (XB + 1) counters (the spare ones are 0) and of nothing else: 771 <= 2 * 512 threads
     vx_bm_block_scan<2>(hx, 3 * (VX_BM_XB + 1), S.wtot);
     if (threadIdx.x < 3) S.lvl_start[threadIdx.x] = hx[threadIdx.x * (VX_BM_XB + 1)];
     if (threadIdx.x == 3) S.lvl_start[3] = n;
     __syncthreads();
+    VX_PREP_STAMP(3);
     // pass 2: position in (class, x) order -> slab; key2 = (class, slab, y bin); histogram over key2
     int per_l[3];
 #pragma unroll
@@ -211,7 +227,9 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
         atomicAdd(&h2[k2], 1);
     }
     __syncthreads();
-    vx_bm_block_scan<(VX_BM_NKEY2 + 255) / 256>(h2, VX_BM_NKEY2, S.wtot);      // 12 per thread covers 256-thread workgroups
+    VX_PREP_STAMP(4);
+    vx_bm_block_scan<(VX_BM_NKEY2 + 255) / 256>(h2, VX_BM_NKEY2, S.wtot);
+    VX_PREP_STAMP(5);      // 12 per thread covers 256-thread workgroups
     vx_bm_rec *recs = w.recs + region;
     for (int i = threadIdx.x; i < n; i += nt) {         // pass 3: scatter (any order inside a bin), tile bounding boxes
         const vx_f4 q = lbox ? lbox[i] : sbox[i];
@@ -224,6 +242,7 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
         atomicMax(&t4[2], vx_f2ord(q.z)); atomicMax(&t4[3], vx_f2ord(q.w));
     }
     __syncthreads();
+    VX_PREP_STAMP(6);
     const int ib = S.ib, si = S.si;
     for (int v = threadIdx.x; v < NT; v += nt) {
         vx_f4 q;
@@ -231,6 +250,8 @@ __device__ __forceinline__ bool vx_bm_prep(vx_bm_prep_smem &S, void *scratch, si
         w.tbb[ib + v] = q; w.item_seg[ib + v] = si;
     }
     __syncthreads();
+    VX_PREP_STAMP(7);
+#undef VX_PREP_STAMP
     return true;
 }
 
