@@ -143,7 +143,11 @@ int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, const float
  * (evidence: scripts/export_check/README.md:54-63,:107,:113); build-authored spec, see
  * oracle/vortex_oracle.py:prior_box_decode.  d_in f32[B,P,4+2L+NC] = loc|landmarks|logits
  * (logit 0 = background), d_priors f32[P,4] normalised cx,cy,w,h.
- * Outputs as vx_yolo_decode with row width D = 6+2L: d_det f32[B,P,D]. */
+ * Outputs as vx_yolo_decode with row width D = 6+2L: d_det f32[B,P,D].
+ * One kernel (round 3): the survivors of a group of rows are listed on chip and written, in row order, straight into
+ * the four output tensors once the groups in front have published their counts; the workspace only holds one ticket
+ * counter per image and one hand-off word per group (a few KB; zeroed by the call itself on `stream`).
+ * Limits: 4+2L+NC <= 63, NC >= 2, P <= VX_MAX_CANDIDATES. */
 size_t vx_prior_decode_workspace_bytes(int B, int P, int n_landmarks);
 int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
                     int n_landmarks, int n_logits, float variance0, float variance1,
@@ -172,7 +176,12 @@ int vx_prior_decode(const float *d_in, const float *d_priors, int B, int P,
  * agree for thresholds that are fp32 values, e.g. fp32 tensors).
  * n_classes == 1 declares class-agnostic NMS (every cls must be 0): no shift, any coordinate range.
  * n_classes is the caller's bound on the class indices (<= 0: VX_MAX_CLASSES); with 4..256 declared classes
- * images beyond the single-launch kernel are partitioned by class before sorting (see vx_nms.hip). */
+ * images beyond the single-launch kernel are partitioned by class before sorting (see vx_nms.hip).
+ * capacity > 16384 (round 3, same results): a class segment of 257..16384 boxes is resolved over the whole chip
+ * (vx_nms_bm.h: spatial tiles -> pair kernel -> edge-list scan; the sweeps remain as fall-back for untame boxes and
+ * overflowing edge lists); top_k > 0 first cuts every image to a score prefix (greedy NMS of a score prefix is the
+ * prefix of the full NMS) and redoes an image whose prefix keeps fewer than top_k boxes on the full path in the same
+ * call -- class ids are then range-checked for the prefix's candidates only. */
 size_t vx_batched_nms_workspace_bytes(int B, int capacity);
 int vx_batched_nms(const float *d_boxes, const float *d_scores, const int64_t *d_cls,
                    const float *d_det, const int32_t *d_counts,
@@ -204,7 +213,8 @@ int vx_softmax_max(const float *d_in, int B, int n_classes, float *d_out, void *
 /* Optimistic variant of vx_batched_nms (same arguments, same results) for capacity > 16384: only the cheap paths are
  * launched.  Without a class count in 4..256: ONE launch; images with more than 16384 candidates are NOT processed.
  * With 4 <= n_classes <= 256: that launch plus the class-partitioned path (histogram, scatter, per-class sort + sweep,
- * run merge / top-k select); images with ONE CLASS of more than 16384 candidates are not processed.  An unprocessed
+ * run merge / top-k select); images with ONE CLASS of more than 16384 candidates are not processed; with top_k > 0
+ * neither is an image whose score prefix keeps fewer than top_k boxes.  An unprocessed
  * image has keep count 0 and VX_STATUS_DEFERRED is set in *d_status -- the caller checks the bit after synchronising
  * and, if set, repeats the call with vx_batched_nms.  No reference counterpart: it spares the ~8 launches of the
  * general path (global sort, per-class sweep), which find nothing to do in the common case. */
