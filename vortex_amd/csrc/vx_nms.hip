@@ -264,26 +264,30 @@ __device__ __forceinline__ void vx_bitonic_sort_lds(u64 *sk, int m, int base, in
     }
 }
 
-// LSD radix sort of the n keys in LDS, ascending, 8-bit digits, in place, for keys that arrive in ascending order of
-// their low 20 bits (the candidate index) -- then a stable sort on the bits above them is the full 64-bit order.  Only
-// the digits that differ between keys are sorted (scores above a threshold share their exponent: three passes for the
-// RetinaFace batch).  A wave owns a contiguous run of 64-key rows and keeps them in registers; a pass:
-//   rank     per row: the lanes with this lane's digit (eight ballots), one returning LDS add per distinct digit on the
-//            wave's own counters -> position of the key among the wave's keys with that digit
-//   scan     the 256 x waves counters in (digit, wave) order, four per thread
+// LSD radix sort of the n keys in LDS, ascending, digits of up to 9 bits, in place, for keys that arrive in ascending
+// order of their low 20 bits (the candidate index) -- then a stable sort on the bits above them is the full 64-bit
+// order.  Only the bits that differ between keys are sorted, the score bits [20, 52) and the class bits [52, 64) as
+// two ranges of their own, each cut into equal digits (scores above a threshold share their exponent: 25 bits = three
+// passes for the RetinaFace batch; dense YOLO: 26 score bits + 7 class bits = 3 + 1 passes, the constant bits between
+// them cost nothing).  A wave owns a contiguous run of 64-key rows and keeps them in registers; a pass:
+//   rank     per row: the lanes with this lane's digit (one ballot per digit bit), one returning LDS add per distinct
+//            digit on the wave's own counters -> position of the key among the wave's keys with that digit
+//   scan     the 512 x waves counters in (digit, wave) order, eight per thread
 //   scatter  every key to counter base + rank, straight from the registers (all keys were read before the first write)
 // against the bitonic network's log2(n)^2 / 2 compare-exchange stages over the padded power of two: 4532 keys take 3
 // passes instead of 91 stages over 8192.
-// hist: (256 * waves + 20) words of LDS.  n <= VX_RADIX_ROWS * 64 * waves.  Ends synchronised.
+// hist: VX_RADIX_HIST_WORDS(waves) words of LDS.  n <= VX_RADIX_ROWS * 64 * waves.  Ends synchronised.
 #define VX_RADIX_ROWS 16
 #define VX_RADIX_MIN 1024             // fewer keys: the bitonic network (mostly register stages) is as fast
-#define VX_RADIX_HIST_WORDS(nw) (256 * (nw) + 20)
+#define VX_RADIX_BITS 9               // A/B (sort cycles, RetinaFace 4532 keys / dense YOLO 2834 keys x 80 classes): 8 bits 47 k / 55 k, 9 bits 49 k / 50 k
+#define VX_RADIX_HIST_WORDS(nw) ((1 << VX_RADIX_BITS) * (nw) + 20)
 __device__ __forceinline__ bool vx_radix_fits(int n, int nw) { return ((n + 63) >> 6) <= VX_RADIX_ROWS * nw; }
 __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist) {
+    constexpr int NB = 1 << VX_RADIX_BITS, PER = NB / 64;           // counters per wave, counters per thread in the scan
     const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rows = ((((n + 63) >> 6) + nw - 1) / nw);             // rows per wave
     const int i0 = wave * rows * 64 + lane;
-    unsigned *s_or = hist + 256 * nw, *s_wsum = s_or + 4;           // [2] differing bits, [16] wave totals of the scan
+    unsigned *s_or = hist + NB * nw, *s_wsum = s_or + 4;            // [2] differing bits, [16] wave totals of the scan
     u64 v[VX_RADIX_ROWS];
     if (threadIdx.x < 2) s_or[threadIdx.x] = 0;
     const u64 k0 = sk[0];
@@ -304,66 +308,94 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
     __syncthreads();
     const u64 var = ((((u64)s_or[1]) << 32) | s_or[0]) >> 20 << 20;
     if (var == 0) return;                                           // one (class, score) for all: already in order
-    const int b_lo = __ffsll((long long)var) - 1, b_hi = 63 - __clzll((long long)var);
-    for (int t = threadIdx.x; t < 256 * nw; t += blockDim.x) hist[t] = 0;
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist) + threadIdx.x * (PER / 4);
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) h4[q] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (int shift = b_lo; shift <= b_hi; shift += 8) {
-        const int nbits = min(8, b_hi - shift + 1);
-        const unsigned mask = (1u << nbits) - 1u;
-        int dest[VX_RADIX_ROWS];                                    // counter index | rank << 16, until the scan is done
-#pragma unroll
-        for (int r = 0; r < VX_RADIX_ROWS; ++r) {
-            if (r < rows) {
-                const bool valid = i0 + r * 64 < n;
-                const unsigned d = (unsigned)(v[r] >> shift) & mask;
-                u64 peers = __ballot(valid);
-#pragma unroll
-                for (int bit = 0; bit < 8; ++bit) {
-                    if (bit < nbits) {
-                        const bool one = (d >> bit) & 1u;
-                        const u64 bm = __ballot(one);
-                        peers &= one ? bm : ~bm;
-                    }
-                }
-                const int below = vx_mbcnt(peers);
-                unsigned old = 0;
-                const int ctr = (int)d * nw + wave;
-                if (valid && below == 0) old = atomicAdd(&hist[ctr], (unsigned)__popcll(peers));
-                old = __shfl(old, __ffsll((long long)peers) - 1);    // from the first lane with this digit
-                dest[r] = ctr | ((int)(old + below) << 16);
-            }
-        }
-        __syncthreads();
-        {   // exclusive scan of the counters in place: four consecutive counters per thread
-            uint4 c = reinterpret_cast<uint4 *>(hist)[threadIdx.x];
-            const unsigned tot = c.x + c.y + c.z + c.w;
-            unsigned incl = tot;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            unsigned pre = lane < wave ? s_wsum[lane] : 0u;         // (wave < 16 <= 64 lanes)
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
-            pre = __shfl(pre, 0);
-            const unsigned run = incl - tot + pre;
-            uint4 o;
-            o.x = run; o.y = run + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
-            reinterpret_cast<uint4 *>(hist)[threadIdx.x] = o;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < VX_RADIX_ROWS; ++r)
-            if (r < rows && i0 + r * 64 < n) sk[hist[dest[r] & 0xFFFF] + (unsigned)(dest[r] >> 16)] = v[r];
-        __syncthreads();
-        if (shift + 8 <= b_hi) {                                    // next pass: keys in their new order, counters at zero
-            reinterpret_cast<uint4 *>(hist)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    // the two bit ranges: scores, then classes
+    const u64 part[2] = {var & ((1ull << 52) - 1ull), var >> 52 << 52};
+    const int last_range = part[1] ? 1 : 0;
+    for (int rg = 0; rg < 2; ++rg) {
+        if (!part[rg]) continue;
+        int shift = __ffsll((long long)part[rg]) - 1;
+        int rem = 64 - __clzll((long long)part[rg]) - shift;        // bits of this range
+        for (int np = (rem + VX_RADIX_BITS - 1) / VX_RADIX_BITS; np > 0; --np) {
+            const int nbits = (rem + np - 1) / np;
+            const unsigned mask = (1u << nbits) - 1u;
+            int dest[VX_RADIX_ROWS];                                // counter index | rank << 16, until the scan is done
 #pragma unroll
             for (int r = 0; r < VX_RADIX_ROWS; ++r) {
-                const int i = i0 + r * 64;
-                if (r < rows && i < n) v[r] = sk[i];
+                if (r < rows) {
+                    const bool valid = i0 + r * 64 < n;
+                    const unsigned d = (unsigned)(v[r] >> shift) & mask;
+                    // lanes whose digit equals this lane's: per bit, the ballot of the bit XNOR this lane's bit (as a 0 / -1
+                    // word: bit-field extract, two v_xnor, two v_and per digit bit)
+                    const u64 pv = __ballot(valid);
+                    unsigned plo = (unsigned)pv, phi = (unsigned)(pv >> 32);
+#pragma unroll
+                    for (int bit = 0; bit < VX_RADIX_BITS; ++bit) {
+                        if (bit < nbits) {
+                            const int t = ((int)(d << (31 - bit))) >> 31;
+                            const u64 bm = __ballot(t != 0);
+                            plo &= ~((unsigned)bm ^ (unsigned)t);
+                            phi &= ~((unsigned)(bm >> 32) ^ (unsigned)t);
+                        }
+                    }
+                    const u64 peers = ((u64)phi << 32) | plo;
+                    const int below = vx_mbcnt(peers);
+                    unsigned old = 0;
+                    const int ctr = (int)d * nw + wave;
+                    if (valid && below == 0) old = atomicAdd(&hist[ctr], (unsigned)__popcll(peers));
+                    old = __shfl(old, __ffsll((long long)peers) - 1);    // from the first lane with this digit
+                    dest[r] = ctr | ((int)(old + below) << 16);
+                }
             }
             __syncthreads();
+            {   // exclusive scan of the counters in place: PER consecutive counters per thread
+                unsigned c[PER], tot = 0;
+#pragma unroll
+                for (int q = 0; q < PER / 4; ++q) {
+                    const uint4 t = h4[q];
+                    c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
+                    tot += t.x + t.y + t.z + t.w;
+                }
+                unsigned incl = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                unsigned pre = lane < wave ? s_wsum[lane] : 0u;     // (wave < 16 <= 64 lanes)
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+                pre = __shfl(pre, 0);
+                unsigned run = incl - tot + pre;
+#pragma unroll
+                for (int q = 0; q < PER / 4; ++q) {
+                    uint4 o;
+                    o.x = run; run += c[4 * q];
+                    o.y = run; run += c[4 * q + 1];
+                    o.z = run; run += c[4 * q + 2];
+                    o.w = run; run += c[4 * q + 3];
+                    h4[q] = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < VX_RADIX_ROWS; ++r)
+                if (r < rows && i0 + r * 64 < n) sk[hist[dest[r] & 0xFFFF] + (unsigned)(dest[r] >> 16)] = v[r];
+            __syncthreads();
+            shift += nbits;
+            rem -= nbits;
+            if (np > 1 || rg < last_range) {                        // another pass: keys in their new order, counters at zero
+#pragma unroll
+                for (int q = 0; q < PER / 4; ++q) h4[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < VX_RADIX_ROWS; ++r) {
+                    const int i = i0 + r * 64;
+                    if (r < rows && i < n) v[r] = sk[i];
+                }
+                __syncthreads();
+            }
         }
     }
 }
