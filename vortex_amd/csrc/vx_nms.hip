@@ -282,7 +282,9 @@ __device__ __forceinline__ void vx_bitonic_sort_lds(u64 *sk, int m, int base, in
 #define VX_RADIX_BITS 9               // A/B (sort cycles, RetinaFace 4532 keys / dense YOLO 2834 keys x 80 classes): 8 bits 47 k / 55 k, 9 bits 49 k / 50 k
 #define VX_RADIX_HIST_WORDS(nw) ((1 << VX_RADIX_BITS) * (nw) + 20)
 __device__ __forceinline__ bool vx_radix_fits(int n, int nw) { return ((n + 63) >> 6) <= VX_RADIX_ROWS * nw; }
-__device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist) {
+// srank (LDS, optional): srank[candidate index] = the key's position once the score bits are sorted, i.e. its rank in
+// the final (score, index) order of the kept list; recorded when the class bits take exactly one pass (returns true).
+__device__ __forceinline__ bool vx_radix_sort_lds(u64 *sk, int n, unsigned *hist, unsigned short *srank = nullptr) {
     constexpr int NB = 1 << VX_RADIX_BITS, PER = NB / 64;           // counters per wave, counters per thread in the scan
     const int lane = vx_lane(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rows = ((((n + 63) >> 6) + nw - 1) / nw);             // rows per wave
@@ -307,7 +309,7 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
     }
     __syncthreads();
     const u64 var = ((((u64)s_or[1]) << 32) | s_or[0]) >> 20 << 20;
-    if (var == 0) return;                                           // one (class, score) for all: already in order
+    if (var == 0) return false;                                     // one (class, score) for all: already in order
     uint4 *h4 = reinterpret_cast<uint4 *>(hist) + threadIdx.x * (PER / 4);
 #pragma unroll
     for (int q = 0; q < PER / 4; ++q) h4[q] = make_uint4(0, 0, 0, 0);
@@ -315,10 +317,19 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
     // the two bit ranges: scores, then classes
     const u64 part[2] = {var & ((1ull << 52) - 1ull), var >> 52 << 52};
     const int last_range = part[1] ? 1 : 0;
+    bool ranked = false;
     for (int rg = 0; rg < 2; ++rg) {
         if (!part[rg]) continue;
         int shift = __ffsll((long long)part[rg]) - 1;
         int rem = 64 - __clzll((long long)part[rg]) - shift;        // bits of this range
+        if (rg == 1 && srank && rem <= VX_RADIX_BITS) {             // v[] holds the keys in (score, index) order here
+#pragma unroll
+            for (int r = 0; r < VX_RADIX_ROWS; ++r) {
+                const int i = i0 + r * 64;
+                if (r < rows && i < n) srank[(unsigned)v[r] & 0xFFFFFu] = (unsigned short)i;
+            }
+            ranked = true;
+        }
         for (int np = (rem + VX_RADIX_BITS - 1) / VX_RADIX_BITS; np > 0; --np) {
             const int nbits = (rem + np - 1) / np;
             const unsigned mask = (1u << nbits) - 1u;
@@ -398,6 +409,7 @@ __device__ __forceinline__ void vx_radix_sort_lds(u64 *sk, int n, unsigned *hist
             }
         }
     }
+    return ranked;
 }
 
 __global__ __launch_bounds__(1024) void vx_k_sort_local(u64 *__restrict__ keys, const int *__restrict__ counts,
@@ -2240,8 +2252,12 @@ __device__ __forceinline__ void vx_nms_image_small(const vx_image_args &a, int b
 // bitmask path): the kept keys of all segments -> global score order (run merge in LDS, or a second sort) -> outputs.
 // n_redo > 0: the image was processed from a score-prefix list; when fewer than top_k boxes were kept it is handed to the
 // paths behind this kernel (sel[b] = n_redo, its full candidate count) instead of being written.
+// srank != nullptr (LDS, from the radix sort; the LDS behind the keys untouched since): srank[candidate] = rank in the
+// final order, so the kept keys are dropped at their rank into `far` and compacted -- no merge rounds.  scratch: LDS for
+// nseg + 1 ints + n / 64 + 1 u64.
 __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int n, int nseg, bool merge, u64 *sk,
-                                              int *s_gcnt, int *s_count2p, int rbits, int n_redo) {
+                                              int *s_gcnt, int *s_count2p, int rbits, int n_redo,
+                                              const unsigned short *srank = nullptr, int *scratch = nullptr, u64 *far = nullptr) {
     const vx_nms_params &p = a.p;
     const int nt = blockDim.x, wave = threadIdx.x >> 6, lane = vx_lane();
     const long long ib = (long long)b * p.cap, ob = (long long)b * p.npad_cap;
@@ -2251,7 +2267,55 @@ __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int
     int &s_count2 = *s_count2p;
 #define VX_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[b * VX_STAMP_WORDS + (k)] = clock64(); } while (0)
     int n2;
-    if (merge) {
+    if (merge && srank && nseg > 1) {
+        int *R = scratch;
+        u64 *bm = reinterpret_cast<u64 *>(scratch + ((nseg + 2) & ~1));
+        const int rows = (n + 63) >> 6;
+        int v[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int s = threadIdx.x * 4 + q; v[q] = s < nseg ? segk[s] : 0; tot += v[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_gcnt[wave] = incl;
+        for (int i = threadIdx.x; i < rows; i += nt) bm[i] = 0ull;
+        __syncthreads();
+        int run = incl - tot;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_gcnt[w2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int s = threadIdx.x * 4 + q; if (s < nseg) R[s] = run; run += v[q]; }
+        if (threadIdx.x == nt - 1) { R[nseg] = run; s_count2 = run; }
+        __syncthreads();
+        n2 = s_count2;
+        // every kept key to the slot of its rank
+        for (int o = threadIdx.x; o < n2; o += nt) {
+            int lo2 = 0, hi2 = nseg;                 // invariant R[lo2] <= o < R[hi2]
+            while (hi2 - lo2 > 1) { int mid = (lo2 + hi2) >> 1; if (R[mid] <= o) lo2 = mid; else hi2 = mid; }
+            const u64 key = k2[seg[lo2] + (o - R[lo2])];
+            const int j = srank[(unsigned)key];
+            far[j] = key;
+            atomicOr((unsigned long long *)&bm[j >> 6], 1ull << (j & 63));
+        }
+        __syncthreads();
+        // compaction in rank order: occupied slots per 64-slot row -> scan -> scatter
+        if (wave == 0) {
+            int c[4], t4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; c[q] = g < rows ? __popcll(bm[g]) : 0; t4 += c[q]; }
+            int inc2 = t4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(inc2, d); if (lane >= d) inc2 += y; }
+            int r2 = inc2 - t4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { int g = lane * 4 + q; if (g < rows) s_gcnt[g] = r2; r2 += c[q]; }
+        }
+        __syncthreads();
+        for (int g = wave; g < rows; g += (nt >> 6)) {
+            const u64 m = bm[g];
+            if ((m >> lane) & 1ull) sk[s_gcnt[g] + vx_mbcnt(m)] = far[g * 64 + lane];
+        }
+        __syncthreads();
+    } else if (merge) {
         // run boundaries R[0..nseg] = exclusive scan of the kept counts (4 per thread, wave scan, wave totals)
         u64 *bufA = sk, *bufB = sk + n;
         int *R = reinterpret_cast<int *>(sk + 2 * (size_t)n);
@@ -2418,10 +2482,19 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __syncthreads();
     VX_STAMP(1);
     // candidates in index order (no prefix list): the radix sort, its counters behind the keys
-    if (!pl && n >= VX_RADIX_MIN && vx_radix_fits(n, nt >> 6) && (size_t)n * sizeof(u64) + 16 + VX_RADIX_HIST_WORDS(nt >> 6) * sizeof(unsigned) <= a.lds_bytes)
-        vx_radix_sort_lds(sk, n, reinterpret_cast<unsigned *>(sk + ((n + 1) & ~1)));
-    else
+    // LDS behind the keys: the radix sort's counters, then (capacity <= 16384 only) the score rank of every candidate
+    // and room for the kept keys: the tail then needs no merge rounds (see vx_image_tail)
+    unsigned *rhist = reinterpret_cast<unsigned *>(sk + ((n + 1) & ~1));
+    unsigned short *srank = reinterpret_cast<unsigned short *>(rhist + ((VX_RADIX_HIST_WORDS(nt >> 6) + 3) & ~3));
+    u64 *far = reinterpret_cast<u64 *>(srank + ((p.cap + 7) & ~7));
+    bool ranked = false;
+    if (!pl && n >= VX_RADIX_MIN && vx_radix_fits(n, nt >> 6) && (size_t)n * sizeof(u64) + 16 + VX_RADIX_HIST_WORDS(nt >> 6) * sizeof(unsigned) <= a.lds_bytes) {
+        const bool room = p.cap <= VX_SORT_CHMAX &&
+                          (size_t)(reinterpret_cast<char *>(far + n) - reinterpret_cast<char *>(sk)) <= a.lds_bytes;
+        ranked = vx_radix_sort_lds(sk, n, rhist, room ? srank : nullptr);
+    } else {
         vx_bitonic_sort_lds(sk, npad, 0, 2, npad);
+    }
     VX_STAMP(2);
     // sorted position -> class-offset box fl32(x + fl32(2049*cls)) (nms.py:94-96) and its area
     vx_f4 *sb = a.sbox + ob;
@@ -2529,7 +2602,8 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
         }
         return;
     }
-    vx_image_tail(a, b, n, nseg, merge, sk, s_gcnt, &s_count2, s_rbits, pl ? n_all : 0);
+    vx_image_tail(a, b, n, nseg, merge, sk, s_gcnt, &s_count2, s_rbits, pl ? n_all : 0,
+                  ranked && nbig == 0 ? srank : nullptr, reinterpret_cast<int *>(rhist), far);
 #undef VX_STAMP
 }
 
