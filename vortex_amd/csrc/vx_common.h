@@ -83,6 +83,33 @@ int vx_internal_cand_finish(const void *stage, const float *stage_lmk, const int
                             vx_finish_params f, float *boxes, float *scores, long long *cls, float *det,
                             int *counts, hipStream_t st);
 
+// What the fused YOLO decode leaves behind for a consumer that packs the per-tile records itself (the single-launch
+// NMS kernel does, sparing the vx_k_cand_finish launch): the staging buffers and the tile -> first-row map of the
+// three scales (tiles of one image: scale 0 planes 0..2, scale 1, scale 2; see vx_fused_tile_row0).
+struct vx_stage_info {
+    const void *stage;                    // vx_rec[B][R]
+    const int *tile_counts;               // [B][tiles]
+    int tiles, R;
+    int tile_base[3], tiles_per_plane[3], tile_cells[3], row_base[3], cells[3];
+};
+__host__ __device__ __forceinline__ int vx_stage_tile_row0(const vx_stage_info &f, int t) {
+    const int si = (t >= f.tile_base[2]) ? 2 : (t >= f.tile_base[1] ? 1 : 0);
+    const int tt = t - f.tile_base[si];
+    const int a = tt / f.tiles_per_plane[si];
+    return f.row_base[si] + a * f.cells[si] + (tt - a * f.tiles_per_plane[si]) * f.tile_cells[si];
+}
+// vx_yolo_fused_decode without its compaction launch (vx_yolo.hip); vx_batched_nms whose single-launch kernel starts
+// from the staged records (vx_nms.hip; capacity == info.R <= 16384, info.tiles <= 256, D == 6, d_counts is written)
+int vx_internal_yolo_fused_stage(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S, int C,
+                                 const float anchors_px[18], float score_threshold, int use_threshold,
+                                 int32_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream,
+                                 vx_stage_info *info);
+int vx_internal_nms_from_stage(const vx_stage_info &info, float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                               int32_t *d_counts, int B, int capacity, int D, int n_classes, float iou_threshold,
+                               int top_k, int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
+                               int out_capacity, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                               void *stream);
+
 __host__ __device__ __forceinline__ int vx_next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;

@@ -2168,6 +2168,10 @@ struct vx_image_args {
     int bm_on;
     const int *plist; // optional [B][VX_PREFIX_CAP]: score-prefix of an image's candidates (vx_k_prefix_select) ...
     const int *pm;    // ... [B] its length, or -1: use all candidates
+    // fin_on != 0 (vx_internal_nms_from_stage): the candidate arrays above are not filled yet -- the workgroup first packs
+    // its image's per-tile records of the fused YOLO decode into them (what vx_k_cand_finish does) and writes counts[b]
+    int fin_on;
+    vx_stage_info fin;
 };
 
 // An image with <= 64 candidates (the common case at the shipped score threshold 0.9: ~10 per image) is one
@@ -2427,6 +2431,55 @@ __device__ __forceinline__ void vx_image_tail(const vx_image_args &a, int b, int
 #undef VX_STAMP
 }
 
+// The compaction pass of the fused YOLO decode inside the NMS kernel (all threads of the workgroup; D == 6): tile counts
+// -> exclusive scan -> every record to its dense, row-ordered position in the candidate arrays of image b.  Returns the
+// image's candidate count (also written to counts[b]); ends synchronised, the arrays visible to the whole workgroup.
+__device__ __forceinline__ int vx_image_finish(const vx_image_args &a, int b) {
+    __shared__ int s_off[257];
+    __shared__ int s_row0[256];
+    __shared__ int s_wt[16];
+    const vx_stage_info &f = a.fin;
+    const int nt = blockDim.x, lane = vx_lane(), wave = threadIdx.x >> 6, nw = nt >> 6;
+    const int t = threadIdx.x;
+    int c = 0, row0 = 0;
+    if (t < f.tiles) { c = f.tile_counts[(long long)b * f.tiles + t]; row0 = vx_stage_tile_row0(f, t); }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) s_wt[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { const int v = s_wt[w]; if (w < wave) base += v; total += v; }
+    if (t < 256) { s_off[t] = base + incl - c; s_row0[t] = row0; }
+    if (t == 0) s_off[256] = total;
+    __syncthreads();
+    const long long ib = (long long)b * a.p.cap;
+    const vx_rec *stage = reinterpret_cast<const vx_rec *>(f.stage) + (long long)b * f.R;
+    float *boxes = const_cast<float *>(a.boxes), *scores = const_cast<float *>(a.scores), *det = const_cast<float *>(a.det);
+    long long *cls = const_cast<long long *>(a.cls);
+    const bool det8 = ((uintptr_t)det & 7) == 0;
+    for (int j = threadIdx.x; j < total; j += nt) {
+        int lo = 0, hi = 256;                        // largest tile index lt with s_off[lt] <= j
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_off[mid] <= j) lo = mid; else hi = mid; }
+        const vx_rec r = stage[s_row0[lo] + (j - s_off[lo])];
+        const long long dst = ib + j;
+        *reinterpret_cast<vx_f4 *>(boxes + dst * 4) = r.a;
+        scores[dst] = r.b.x;
+        const int ci = __float_as_int(r.b.z);
+        cls[dst] = (long long)ci;
+        float *d = det + dst * 6;
+        if (det8) {
+            float2 *d2 = reinterpret_cast<float2 *>(d);
+            d2[0] = make_float2(r.a.x, r.a.y); d2[1] = make_float2(r.a.z, r.a.w); d2[2] = make_float2(r.b.y, (float)ci);
+        } else {
+            d[0] = r.a.x; d[1] = r.a.y; d[2] = r.a.z; d[3] = r.a.w; d[4] = r.b.y; d[5] = (float)ci;
+        }
+    }
+    if (threadIdx.x == 0) const_cast<int *>(a.counts)[b] = total;
+    __syncthreads();                                 // (workgroup-scope release/acquire of the stores above)
+    return total;
+}
+
 __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
@@ -2439,7 +2492,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
     const vx_nms_params &p = a.p;
     const int b = blockIdx.x, nt = blockDim.x;
-    const int n_all = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    const int n_all = a.fin_on ? vx_image_finish(a, b) : (a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap);
     // score-prefix list (top_k on a large input, see vx_k_prefix_select): this kernel works on the list only
     const int pmb = a.pm ? a.pm[b] : -1;
     const int *pl = (pmb > 0 && pmb <= VX_PREFIX_CAP) ? a.plist + (long long)b * VX_PREFIX_CAP : nullptr;
@@ -2763,10 +2816,14 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
                        const int32_t *d_counts, int B, int capacity, int D, int n_classes,
                        float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
                        int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
-                       size_t workspace_bytes, void *stream, int small_only) {
+                       size_t workspace_bytes, void *stream, int small_only, const vx_stage_info *fin = nullptr) {
     if (!d_boxes || !d_scores || !d_cls || !d_det || !d_keep_idx || !d_out_det || !d_keep_counts || !d_status ||
         !d_workspace)
         return VX_ERR_INVALID_ARG;
+    // candidates still staged per tile: only the single-launch kernel packs them (the caller checked the rest)
+    if (fin && (vx_next_pow2(capacity) > VX_SORT_CHMAX || fin->tiles > 256 || fin->R != capacity || D != 6 || !d_counts ||
+                ((uintptr_t)d_det & 3)))
+        return VX_ERR_UNSUPPORTED;
     if (B <= 0 || capacity <= 0 || D <= 0 || out_capacity <= 0) return VX_ERR_INVALID_ARG;
     if (!(iou_threshold >= 0.0f)) return VX_ERR_UNSUPPORTED;     // see header: class segmentation needs thr >= 0
     if (capacity > VX_MAX_CANDIDATES || B > 65535) return VX_ERR_UNSUPPORTED;
@@ -2808,6 +2865,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.keys1 = w.keys1; a.iou_count = vx_iou_counter();
         a.bm = w.bm; a.bm_on = w.bm_on;
         a.plist = nullptr; a.pm = nullptr;
+        a.fin_on = fin ? 1 : 0;
+        if (fin) a.fin = *fin;
         if (!all_fit && top_k > 0) {                 // top_k on a large input: score prefix first (see vx_k_prefix_select)
             vx_prof_begin(VX_PROF_NMS_KEYS, st);
             hipLaunchKernelGGL(vx_k_prefix_thr, dim3(B), dim3(1024), 0, st, d_scores, d_counts, p, w.pthr, w.pm);
@@ -2953,6 +3012,18 @@ extern "C" int vx_batched_nms(const float *d_boxes, const float *d_scores, const
                               size_t workspace_bytes, void *stream) {
     return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
                        d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, d_workspace, workspace_bytes, stream, 0);
+}
+
+// vx_batched_nms whose single-launch kernel starts from the per-tile records of the fused YOLO decode (declared in
+// vx_common.h): spares the vx_k_cand_finish launch; the candidate arrays and d_counts are written by the kernel.
+int vx_internal_nms_from_stage(const vx_stage_info &info, float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                               int32_t *d_counts, int B, int capacity, int D, int n_classes, float iou_threshold,
+                               int top_k, int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
+                               int out_capacity, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                               void *stream) {
+    return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
+                       d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, d_workspace, workspace_bytes, stream, 0,
+                       &info);
 }
 
 // Optimistic variant for capacities beyond the single-launch kernel: ONE launch; an image with more than 16384

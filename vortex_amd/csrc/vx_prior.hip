@@ -95,6 +95,7 @@ __device__ __forceinline__ void vx_prior_emit(vx_prior_smem<LIST> &S, const vx_f
             bx.x = cx - hw; bx.y = cy - hh; bx.z = cx + hw; bx.w = cy + hh;
             float2 *d2 = reinterpret_cast<float2 *>(stage + threadIdx.x * D);
             d2[0] = make_float2(bx.x, bx.y); d2[1] = make_float2(bx.z, bx.w); d2[2] = make_float2(cf, (float)cid);
+#pragma nounroll
             for (int qq = 0; qq < p.L; ++qq)
                 d2[3 + qq] = make_float2(pr.x + (srow[4 + 2 * qq] * p.v0) * pr.z, pr.y + (srow[5 + 2 * qq] * p.v0) * pr.w);
         }
@@ -128,12 +129,15 @@ __device__ __forceinline__ void vx_prior_emit(vx_prior_smem<LIST> &S, const vx_f
         const int nf = min(256, total - j0) * D;                    // floats of this batch's result rows
         float *dg = det + dst0 * D;
         if (det16) {
+#pragma nounroll
             for (int u = threadIdx.x; u < (nf >> 2); u += 256)
                 reinterpret_cast<vx_v4 *>(dg)[u] = reinterpret_cast<const vx_v4 *>(stage)[u];
         } else if (det8) {
+#pragma nounroll
             for (int u = threadIdx.x; u < (nf >> 1); u += 256)
                 reinterpret_cast<float2 *>(dg)[u] = reinterpret_cast<const float2 *>(stage)[u];
         } else {
+#pragma nounroll
             for (int u = threadIdx.x; u < nf; u += 256) dg[u] = stage[u];
         }
         j0 += 256;

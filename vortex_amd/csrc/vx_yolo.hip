@@ -825,20 +825,19 @@ extern "C" size_t vx_yolo_fused_workspace_bytes(int B, int S) {
     return vx_stage_bytes(B, vx_yolo_rows(S), vx_fused_tiles(S), 0);
 }
 
-extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
-                                    int C, const float anchors_px[18], float score_threshold, int use_threshold,
-                                    float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
-                                    int32_t *d_counts, int32_t *d_status, void *d_workspace,
-                                    size_t workspace_bytes, void *stream) {
-    if (!d_head0 || !d_head1 || !d_head2 || !anchors_px || !d_boxes || !d_scores || !d_cls || !d_det ||
-        !d_counts || !d_status || !d_workspace)
-        return VX_ERR_INVALID_ARG;
+// info != nullptr: the decode kernel only; the caller packs the staged records (vx_stage_info)
+static int vx_fused_decode_impl(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                                int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                                float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                                int32_t *d_counts, int32_t *d_status, void *d_workspace,
+                                size_t workspace_bytes, void *stream, vx_stage_info *info) {
+    if (!d_head0 || !d_head1 || !d_head2 || !anchors_px || !d_status || !d_workspace) return VX_ERR_INVALID_ARG;
+    if (!info && (!d_boxes || !d_scores || !d_cls || !d_det || !d_counts)) return VX_ERR_INVALID_ARG;
     if (B <= 0 || S < 32 || C <= 0) return VX_ERR_INVALID_ARG;
     if (C > VX_MAX_CLASSES || B > 65535) return VX_ERR_UNSUPPORTED;
-    if (((uintptr_t)d_head0 & 3) || ((uintptr_t)d_head1 & 3) || ((uintptr_t)d_head2 & 3) ||
-        ((uintptr_t)d_boxes & 15) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_det & 3) ||
-        ((uintptr_t)d_cls & 7))
+    if (((uintptr_t)d_head0 & 3) || ((uintptr_t)d_head1 & 3) || ((uintptr_t)d_head2 & 3) || ((uintptr_t)d_workspace & 255))
         return VX_ERR_ALIGNMENT;
+    if (!info && (((uintptr_t)d_boxes & 15) || ((uintptr_t)d_det & 3) || ((uintptr_t)d_cls & 7))) return VX_ERR_ALIGNMENT;
     vx_fused_params p = {};
     int rc = vx_fused_setup(p, d_head0, d_head1, d_head2, B, S, C, anchors_px);
     if (rc != VX_OK) return rc;
@@ -872,6 +871,14 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
         hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
     vx_prof_end(VX_PROF_FUSED, st);
+    if (info) {
+        info->stage = stage; info->tile_counts = tile_counts; info->tiles = p.tiles_per_img; info->R = p.R;
+        for (int i = 0; i < 3; ++i) {
+            info->tile_base[i] = p.s[i].tile_base; info->tiles_per_plane[i] = p.s[i].tiles_per_plane;
+            info->tile_cells[i] = p.s[i].tile_cells; info->row_base[i] = p.s[i].row_base; info->cells[i] = p.s[i].cells;
+        }
+        return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+    }
     vx_finish_params f;
     f.R = p.R; f.tiles_per_img = p.tiles_per_img; f.D = 6; f.L = 0; f.uniform_tile_rows = 0;
     vx_prof_begin(VX_PROF_FINISH, st);
@@ -879,4 +886,22 @@ extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, 
                        d_boxes, d_scores, (long long *)d_cls, d_det, d_counts);
     vx_prof_end(VX_PROF_FINISH, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
+extern "C" int vx_yolo_fused_decode(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
+                                    int C, const float anchors_px[18], float score_threshold, int use_threshold,
+                                    float *d_boxes, float *d_scores, int64_t *d_cls, float *d_det,
+                                    int32_t *d_counts, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return vx_fused_decode_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, d_boxes,
+                                d_scores, d_cls, d_det, d_counts, d_status, d_workspace, workspace_bytes, stream, nullptr);
+}
+
+int vx_internal_yolo_fused_stage(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S, int C,
+                                 const float anchors_px[18], float score_threshold, int use_threshold,
+                                 int32_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream,
+                                 vx_stage_info *info) {
+    if (!info) return VX_ERR_INVALID_ARG;
+    return vx_fused_decode_impl(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, d_status, d_workspace, workspace_bytes, stream, info);
 }
