@@ -98,6 +98,21 @@ __host__ __device__ __forceinline__ int vx_stage_tile_row0(const vx_stage_info &
     const int a = tt / f.tiles_per_plane[si];
     return f.row_base[si] + a * f.cells[si] + (tt - a * f.tiles_per_plane[si]) * f.tile_cells[si];
 }
+// Packing inside the single-launch NMS kernel (vx_pipeline.hip): the kept rows of the images back to back in `dst`, the
+// 2B+1 meta words (counts | keep_counts | status) completed and mirrored by the workgroup that finishes last.
+//   sync: int[VX_PACK_SYNC_WORDS(B)], ZERO at launch -- [2] the call chain's status word (the kernels of the chain
+//         accumulate their status here), [HDR + b * STRIDE] keep count of image b, published (a line of its own),
+//         [HDR + B * STRIDE + b] image b's rows are copied
+// Only for B <= the device's compute units (all workgroups resident at once: waiting on a lower image cannot starve it).
+#define VX_PACK_HDR 64
+#define VX_PACK_STRIDE 32
+#define VX_PACK_SYNC_WORDS(B) (VX_PACK_HDR + (size_t)(B) * (VX_PACK_STRIDE + 1))
+struct vx_pack_info {
+    float *dst;
+    int *sync;
+    int *meta;                            // device: counts[B] | keep_counts[B] | status
+    int *mirror;                          // optional copy of the 2B+1 words (pinned host memory)
+};
 // vx_yolo_fused_decode without its compaction launch (vx_yolo.hip); vx_batched_nms whose single-launch kernel starts
 // from the staged records (vx_nms.hip; capacity == info.R <= 16384, info.tiles <= 256, D == 6, d_counts is written)
 int vx_internal_yolo_fused_stage(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S, int C,
@@ -108,7 +123,7 @@ int vx_internal_nms_from_stage(const vx_stage_info &info, float *d_boxes, float 
                                int32_t *d_counts, int B, int capacity, int D, int n_classes, float iou_threshold,
                                int top_k, int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
                                int out_capacity, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
-                               void *stream);
+                               void *stream, const vx_pack_info *pack);
 
 __host__ __device__ __forceinline__ int vx_next_pow2(int n) {
     int p = 1;

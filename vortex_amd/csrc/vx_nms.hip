@@ -2172,6 +2172,9 @@ struct vx_image_args {
     // its image's per-tile records of the fused YOLO decode into them (what vx_k_cand_finish does) and writes counts[b]
     int fin_on;
     vx_stage_info fin;
+    // pack_on != 0: the kernel also packs the kept rows (vx_pack_info; images are assigned by ticket, see vx_image_pack)
+    int pack_on;
+    vx_pack_info pack;
 };
 
 // An image with <= 64 candidates (the common case at the shipped score threshold 0.9: ~10 per image) is one
@@ -2480,7 +2483,7 @@ __device__ __forceinline__ int vx_image_finish(const vx_image_args &a, int b) {
     return total;
 }
 
-__global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
+__device__ __forceinline__ void vx_nms_image_body(const vx_image_args &a, const int b) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];
     __shared__ vx_async_smem A;
     __shared__ union { vx_spatial_smem sp; vx_bm_prep_smem prep; } U;      // the spatial sweep and the bitmask prep never overlap
@@ -2491,7 +2494,7 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
     __shared__ u64 s_wmask[16][64];
     __shared__ unsigned short s_pair_lut[VX_NPAIRS64];
     const vx_nms_params &p = a.p;
-    const int b = blockIdx.x, nt = blockDim.x;
+    const int nt = blockDim.x;
     const int n_all = a.fin_on ? vx_image_finish(a, b) : (a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap);
     // score-prefix list (top_k on a large input, see vx_k_prefix_select): this kernel works on the list only
     const int pmb = a.pm ? a.pm[b] : -1;
@@ -2660,6 +2663,91 @@ __global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
 #undef VX_STAMP
 }
 
+// vx_k_pack_rows inside the NMS kernel.  The packed rows of image b start behind those of the images in front of it, so a
+// workgroup publishes its keep count in one word and sums the words in front of it (polling those not there yet); when
+// its rows are copied it sets a second word, and the workgroup of the last image waits for all of those before it
+// completes the meta words (status) and mirrors them for the host.  No workgroup waits before it has published, and the
+// host only takes this path when all B workgroups are resident at once (B <= compute units), so every wait ends.
+// (Tickets and a "finished" counter were measured first: 256 returning atomics on one address cost 70 us.)
+__device__ __forceinline__ void vx_image_pack(const vx_image_args &a, int b) {
+    __shared__ int s_off;
+    const vx_nms_params &p = a.p;
+    const int lane = vx_lane(), wave = threadIdx.x >> 6, nt = blockDim.x;
+    // (one 128-byte line per count word: 255 workgroups polling eight shared lines serialised on one memory channel,
+    // 65 us for 256 images)
+    int *flags = a.pack.sync + VX_PACK_HDR, *fin = flags + p.B * VX_PACK_STRIDE;
+    __syncthreads();                                 // the body's stores (keep_counts[b], the image's out_det rows) are visible
+    const int n = vx_clamp_count(a.keep_counts[b], p.out_cap);
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[b * VX_PACK_STRIDE], (n << 1) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+        int acc = 0;
+        for (int gb = 0; gb < b; gb += 256) {        // four words per lane in flight (B <= 256: one round)
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = gb + k * 64 + lane;
+                v[k] = g < b ? __hip_atomic_load(&flags[g * VX_PACK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = gb + k * 64 + lane;
+                while ((v[k] & 1) == 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    v[k] = __hip_atomic_load(&flags[g * VX_PACK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                acc += v[k] >> 1;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) s_off = acc;
+    }
+    __syncthreads();
+    const float *src = a.out_det + (long long)b * p.out_cap * p.D;
+    float *dst = a.pack.dst + (long long)s_off * p.D;
+    const int nf = n * p.D;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        for (int i = threadIdx.x; i < (nf >> 1); i += nt)
+            __builtin_nontemporal_store(reinterpret_cast<const v2 *>(src)[i], reinterpret_cast<v2 *>(dst) + i);
+        if ((nf & 1) && threadIdx.x == 0) dst[nf - 1] = src[nf - 1];
+    } else {
+        for (int i = threadIdx.x; i < nf; i += nt) __builtin_nontemporal_store(src[i], dst + i);
+    }
+    // "rows copied" word of this image; it carries the image's candidate count for the mirror.  No fence anywhere: an
+    // agent-scope release on gfx950 writes the whole L2 back (256 of them cost 65 us); the words that other workgroups
+    // read are agent-scope atomics themselves, everything else is read after the kernel.
+    const int nc = a.counts ? vx_clamp_count(a.counts[b], p.cap) : p.cap;
+    if (b != p.B - 1) {
+        __syncthreads();                             // (waits for this workgroup's stores, the status atomic included)
+        if (threadIdx.x == 0) __hip_atomic_store(&fin[b], (nc << 1) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // the last image's workgroup: once every other workgroup has finished the meta words are final -- it mirrors them
+    // from the published words
+    int *mirror = a.pack.mirror;
+    for (int g = threadIdx.x; g < p.B; g += nt) {
+        int c = (nc << 1) | 1, k = (n << 1) | 1;
+        if (g < p.B - 1) {
+            while (((c = __hip_atomic_load(&fin[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1) == 0)
+                __builtin_amdgcn_s_sleep(8);
+            k = __hip_atomic_load(&flags[g * VX_PACK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mirror) { mirror[g] = c >> 1; mirror[p.B + g] = k >> 1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int st = __hip_atomic_load(&a.pack.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.pack.meta[2 * p.B] = st;
+        if (mirror) mirror[2 * p.B] = st;
+    }
+}
+
+__global__ __launch_bounds__(1024) void vx_k_nms_image(vx_image_args a) {
+    vx_nms_image_body(a, blockIdx.x);
+    if (a.pack_on) vx_image_pack(a, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Bitmask path, last step on the image route: one workgroup per image that vx_k_nms_image left pending.  Every exported
 // segment is resolved from its edge list (vx_bm_scan; the chain sweep when the list overflowed), its kept keys go, in
@@ -2816,7 +2904,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
                        const int32_t *d_counts, int B, int capacity, int D, int n_classes,
                        float iou_threshold, int top_k, int64_t *d_keep_idx, float *d_out_det,
                        int32_t *d_keep_counts, int out_capacity, int32_t *d_status, void *d_workspace,
-                       size_t workspace_bytes, void *stream, int small_only, const vx_stage_info *fin = nullptr) {
+                       size_t workspace_bytes, void *stream, int small_only, const vx_stage_info *fin = nullptr,
+                       const vx_pack_info *pack = nullptr) {
     if (!d_boxes || !d_scores || !d_cls || !d_det || !d_keep_idx || !d_out_det || !d_keep_counts || !d_status ||
         !d_workspace)
         return VX_ERR_INVALID_ARG;
@@ -2824,6 +2913,7 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
     if (fin && (vx_next_pow2(capacity) > VX_SORT_CHMAX || fin->tiles > 256 || fin->R != capacity || D != 6 || !d_counts ||
                 ((uintptr_t)d_det & 3)))
         return VX_ERR_UNSUPPORTED;
+    if (pack && (vx_next_pow2(capacity) > VX_SORT_CHMAX || !pack->dst || !pack->sync || !pack->meta)) return VX_ERR_UNSUPPORTED;
     if (B <= 0 || capacity <= 0 || D <= 0 || out_capacity <= 0) return VX_ERR_INVALID_ARG;
     if (!(iou_threshold >= 0.0f)) return VX_ERR_UNSUPPORTED;     // see header: class segmentation needs thr >= 0
     if (capacity > VX_MAX_CANDIDATES || B > 65535) return VX_ERR_UNSUPPORTED;
@@ -2867,6 +2957,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.plist = nullptr; a.pm = nullptr;
         a.fin_on = fin ? 1 : 0;
         if (fin) a.fin = *fin;
+        a.pack_on = pack ? 1 : 0;
+        if (pack) a.pack = *pack;
         if (!all_fit && top_k > 0) {                 // top_k on a large input: score prefix first (see vx_k_prefix_select)
             vx_prof_begin(VX_PROF_NMS_KEYS, st);
             hipLaunchKernelGGL(vx_k_prefix_thr, dim3(B), dim3(1024), 0, st, d_scores, d_counts, p, w.pthr, w.pm);
@@ -3020,10 +3112,10 @@ int vx_internal_nms_from_stage(const vx_stage_info &info, float *d_boxes, float 
                                int32_t *d_counts, int B, int capacity, int D, int n_classes, float iou_threshold,
                                int top_k, int64_t *d_keep_idx, float *d_out_det, int32_t *d_keep_counts,
                                int out_capacity, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
-                               void *stream) {
+                               void *stream, const vx_pack_info *pack) {
     return vx_nms_impl(d_boxes, d_scores, d_cls, d_det, d_counts, B, capacity, D, n_classes, iou_threshold, top_k,
                        d_keep_idx, d_out_det, d_keep_counts, out_capacity, d_status, d_workspace, workspace_bytes, stream, 0,
-                       &info);
+                       &info, pack);
 }
 
 // Optimistic variant for capacities beyond the single-launch kernel: ONE launch; an image with more than 16384

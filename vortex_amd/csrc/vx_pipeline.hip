@@ -17,6 +17,7 @@ struct vx_pipe_ws {
     float *boxes, *scores, *det, *out_det;
     int64_t *cls, *keep_idx;
     char *nms; size_t nms_bytes;
+    int *sync; size_t sync_bytes;        // vx_pack_info::sync (tickets, finished count, status, one word per image)
     size_t total;
 };
 
@@ -37,6 +38,8 @@ static vx_pipe_ws vx_pipe_carve(void *ws, int B, int S, int out_cap) {
     w.keep_idx = (int64_t *)(p + off); off += vx_al(m * sizeof(int64_t));
     w.out_det = (float *)(p + off); off += vx_al(m * 6 * sizeof(float));
     w.nms = p + off; off += vx_al(w.nms_bytes);
+    w.sync_bytes = vx_al(VX_PACK_SYNC_WORDS(B) * sizeof(int));
+    w.sync = (int *)(p + off); off += w.sync_bytes;
     w.total = off;
     return w;
 }
@@ -67,6 +70,19 @@ static hipEvent_t vx_decoded_event() {
     return ev[dev];
 }
 
+// compute units of the current device (cached per device)
+static int vx_pipe_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cus[dev] = n;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
 static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float *d_head2, int B, int S,
                         int C, const float anchors_px[18], float score_threshold, int use_threshold,
                         float iou_threshold, int top_k, float *d_packed, int32_t *d_meta,
@@ -81,12 +97,20 @@ static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float 
     if (workspace_bytes < w.total) return VX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int32_t *counts = d_meta, *keep_counts = d_meta + B, *status = d_meta + 2 * B;
-    // only the status word is accumulated (atomicOr); counts and keep_counts are written for every image.  A memset
-    // of all 2B+1 words is split by the runtime into two fill kernels (aligned body + 4-byte tail), ~4 us each.
-    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return VX_ERR_LAUNCH;
     // R <= 16384 (every YOLOv3 size up to 512): the single-launch NMS kernel packs the decode's per-tile records itself
-    // (one launch less per batch: ~6 us of a 275 us step, ~5 us of a batch-1 step)
+    // (one launch less per batch) ...
     const bool from_stage = vx_next_pow2(R) <= 16384;
+    // ... and packs the kept rows too when its B workgroups are all resident at once
+    const bool pack_in_kernel = from_stage && B <= vx_pipe_cus();
+    if (pack_in_kernel) {
+        if (hipMemsetAsync(w.sync, 0, w.sync_bytes, st) != hipSuccess) return VX_ERR_LAUNCH;
+        status = w.sync + 2;
+    // (the status word of the chain then lives next to that kernel's hand-off words: ONE fill of whole 256-byte lines)
+    // Otherwise only the status word is cleared (it is accumulated by atomicOr; counts and keep_counts are written for
+    // every image; a memset of all 2B+1 words is split by the runtime into two fill kernels, ~4 us each).
+    } else if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
+        return VX_ERR_LAUNCH;
+    }
     vx_stage_info info = {};
     int rc = from_stage
                  ? vx_internal_yolo_fused_stage(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold,
@@ -102,10 +126,15 @@ static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float 
             return VX_ERR_LAUNCH;
         stream = tail_stream;
     }
-    if (from_stage && info.tiles <= 256)
+    if (from_stage && info.tiles <= 256) {
+        vx_pack_info pk;
+        pk.dst = d_packed; pk.sync = w.sync; pk.meta = d_meta; pk.mirror = meta_mirror;
         rc = vx_internal_nms_from_stage(info, w.boxes, w.scores, w.cls, w.det, counts, B, R, 6, C, iou_threshold, top_k,
-                                        w.keep_idx, w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream);
-    else if (from_stage)
+                                        w.keep_idx, w.out_det, keep_counts, out_cap, status, w.nms, w.nms_bytes, stream,
+                                        pack_in_kernel ? &pk : nullptr);
+        if (rc != VX_OK) return rc;
+        if (pack_in_kernel) return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+    } else if (from_stage)
         return VX_ERR_UNSUPPORTED;                     // (cannot happen: R <= 16384 rows are at most 3 * 22 tiles)
     else
         rc = (use_threshold & VX_POSTPROCESS_NMS_OPTIMISTIC)
