@@ -261,7 +261,9 @@ int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, int capacit
  *   d_meta   i32[2B+1]       : counts[B] | keep_counts[B] | status  (every word written here; status bits as above)
  *   meta_mirror (optional)   : the same 2B+1 words copied to this device-accessible address (pinned host memory)
  * use_threshold takes the VX_DECODE_* bits and VX_POSTPROCESS_NMS_OPTIMISTIC.  The workspace holds every
- * intermediate. */
+ * intermediate.  Up to 16384 rows per image (S <= 512) the chain is two launches behind one fill: the decode, then
+ * the single-launch NMS kernel, which also packs the decode's per-tile records and -- with B <= the device's
+ * compute units -- the kept rows (no vx_k_cand_finish / vx_k_pack_rows launch; same outputs). */
 size_t vx_yolo_fused_postprocess_workspace_bytes(int B, int S, int top_k);
 int vx_yolo_fused_postprocess(const float *d_head0, const float *d_head1, const float *d_head2,
                               int B, int S, int C, const float anchors_px[18],
