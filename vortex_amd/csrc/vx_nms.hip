@@ -3178,13 +3178,16 @@ extern "C" int vx_batched_nms_noalloc(const float *d_boxes, const float *d_score
 // ------------------------------------------------------------------------------------------------
 // Tuple packing (the `tuple(results)` of base_postprocess.py:131-138 without B Python slices):
 // rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
-#define VX_PACK_ROWS 2048
+#define VX_PACK_ROWS 256
+#define VX_PACK_MAXG 16              // workgroups per image
 __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ src, const int *__restrict__ counts,
                                                       int B, int cap, int D, float *__restrict__ dst,
                                                       int *__restrict__ total, const int *__restrict__ meta_src,
                                                       int *__restrict__ meta_dst, int n_meta) {
     __shared__ int s_part[256];
-    // workgroup (g, b) copies rows [g*VX_PACK_ROWS, (g+1)*VX_PACK_ROWS) of image b; most leave at once
+    // workgroup (g, b) copies the row chunks g, g + gridDim.x, ... (VX_PACK_ROWS rows each) of image b: a bounded grid
+    // (the keep counts are not known on the host: one workgroup per possible chunk meant thousands of empty ones for a
+    // capacity of 50 400) and enough workgroups per image for a few thousand kept rows
     const int b = blockIdx.y, g = blockIdx.x;
     const int n = vx_clamp_count(counts[b], cap);
     if (g > 0 && g * VX_PACK_ROWS >= n) return;
@@ -3202,18 +3205,20 @@ __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ 
     }
     const long long off = s_part[0];
     if (b == B - 1 && g == 0 && threadIdx.x == 0 && total) *total = (int)off + n;
-    const int r0 = g * VX_PACK_ROWS, r1 = min(n, r0 + VX_PACK_ROWS);
-    const float *s = src + ((long long)b * cap + r0) * D;
-    float *d = dst + (off + r0) * D;
-    // final output, read by the host side only: non-temporal stores keep it from displacing the next batch's streams
-    const int nf = (r1 - r0) * D;
-    if ((((uintptr_t)s | (uintptr_t)d) & 7) == 0) {
-        typedef float v2 __attribute__((ext_vector_type(2)));
-        for (int i = threadIdx.x; i < (nf >> 1); i += 256)
-            __builtin_nontemporal_store(reinterpret_cast<const v2 *>(s)[i], reinterpret_cast<v2 *>(d) + i);
-        if ((nf & 1) && threadIdx.x == 0) d[nf - 1] = s[nf - 1];
-    } else {
-        for (int i = threadIdx.x; i < nf; i += 256) __builtin_nontemporal_store(s[i], d + i);
+    for (int r0 = g * VX_PACK_ROWS; r0 < n; r0 += gridDim.x * VX_PACK_ROWS) {
+        const int r1 = min(n, r0 + VX_PACK_ROWS);
+        const float *s = src + ((long long)b * cap + r0) * D;
+        float *d = dst + (off + r0) * D;
+        // final output, read by the host side only: non-temporal stores keep it from displacing the next batch's streams
+        const int nf = (r1 - r0) * D;
+        if ((((uintptr_t)s | (uintptr_t)d) & 7) == 0) {
+            typedef float v2 __attribute__((ext_vector_type(2)));
+            for (int i = threadIdx.x; i < (nf >> 1); i += 256)
+                __builtin_nontemporal_store(reinterpret_cast<const v2 *>(s)[i], reinterpret_cast<v2 *>(d) + i);
+            if ((nf & 1) && threadIdx.x == 0) d[nf - 1] = s[nf - 1];
+        } else {
+            for (int i = threadIdx.x; i < nf; i += 256) __builtin_nontemporal_store(s[i], d + i);
+        }
     }
 }
 
@@ -3225,7 +3230,9 @@ extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, 
     if (B > 65535) return VX_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_PACK, st);
-    hipLaunchKernelGGL(vx_k_pack_rows, dim3((capacity + VX_PACK_ROWS - 1) / VX_PACK_ROWS, B), dim3(256), 0, st, d_src,
+    int gx = (capacity + VX_PACK_ROWS - 1) / VX_PACK_ROWS;
+    if (gx > VX_PACK_MAXG) gx = VX_PACK_MAXG;
+    hipLaunchKernelGGL(vx_k_pack_rows, dim3(gx, B), dim3(256), 0, st, d_src,
                        d_counts, B, capacity, D, d_dst, d_total, d_meta_src, meta_dst, n_meta);
     vx_prof_end(VX_PROF_PACK, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
