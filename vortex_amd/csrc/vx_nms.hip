@@ -1485,6 +1485,8 @@ struct vx_part_args {
                            //    hist[b][c] (the run merge below takes them from there); 0: keys2 through count2
     vx_bm_ws bm;           // bitmask path (vx_nms_bm.h): large segments are exported instead of swept when bm_on != 0
     int bm_on;
+    int *big_count, *big_list;   // segments of more than VX_PART_SMALL keys, (b << 8) | c, listed by the first vx_k_part_sweep
+    int big_cap;                 // launch for the second (a zeroed counter; nullptr: the second launch covers every (class, image))
 };
 
 __device__ __forceinline__ int vx_part_class(long long c, int n_classes, bool &bad) {
@@ -1579,15 +1581,16 @@ __global__ __launch_bounds__(1024) void vx_k_part_scatter(vx_part_args a) {
 // (512-thread variant: three to four workgroups per CU wanted -- 7 waves per SIMD, 72 registers (64 are out of reach); the chain-sweep fall-back spills
 // under that budget, the sort / gather / prep that every segment runs do not)
 template <int LDS_KEYS, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_sweep(vx_part_args a) {
-    extern __shared__ __attribute__((aligned(16))) u64 sk[];
-    __shared__ vx_async_smem A;
-    __shared__ vx_bm_prep_smem PREP;
-    __shared__ int s_rbits;
-    const int b = blockIdx.y, c = blockIdx.x;
+__device__ __forceinline__ void vx_part_sweep_one(const vx_part_args &a, const int b, const int c, u64 *sk, vx_async_smem &A,
+                                                  vx_bm_prep_smem &PREP, int &s_rbits) {
     if (a.sel[b] == 0 || a.sel2[b] != 0) return;
     const int lo = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c];
     const int len = a.segstart[b * (VX_PART_MAX_CLASSES + 1) + c + 1] - lo;
+    // the first launch lists the segments of the second
+    if (LDS_KEYS <= VX_PART_SMALL && a.big_count && len > LDS_KEYS && len <= VX_SORT_CHMAX && threadIdx.x == 0) {
+        const int i = atomicAdd(a.big_count, 1);
+        if (i < a.big_cap) a.big_list[i] = (b << 8) | c;
+    }
     // this launch's share: (0, VX_PART_SMALL] or (VX_PART_SMALL, VX_SORT_CHMAX]
     if (len <= 0 || len > LDS_KEYS || (LDS_KEYS > VX_PART_SMALL && len <= VX_PART_SMALL)) return;
     const vx_nms_params &p = a.p;
@@ -1630,6 +1633,27 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_swe
         vx_async_emit(A, kseg, k2, c2, kc);
     }
     if (threadIdx.x == 0) vx_status_or(a.status, s_rbits);
+}
+
+// Launched twice: <VX_PART_SMALL, 512> over every (class, image) for the segments of up to VX_PART_SMALL keys, then
+// <VX_SORT_CHMAX, 1024> for the larger ones -- over the list the first launch made (a bounded grid: a grid of classes x
+// images 128-KiB workgroups that nearly all leave at once cost 19 us on the FPN-SSD batch).
+template <int LDS_KEYS, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 7 : 4) void vx_k_part_sweep(vx_part_args a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];
+    __shared__ vx_async_smem A;
+    __shared__ vx_bm_prep_smem PREP;
+    __shared__ int s_rbits;
+    if (LDS_KEYS <= VX_PART_SMALL || !a.big_count) {
+        vx_part_sweep_one<LDS_KEYS, THREADS>(a, blockIdx.y, blockIdx.x, sk, A, PREP, s_rbits);
+        return;
+    }
+    const int n = min(*a.big_count, a.big_cap);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int e = a.big_list[i];
+        vx_part_sweep_one<LDS_KEYS, THREADS>(a, e >> 8, e & 255, sk, A, PREP, s_rbits);
+        __syncthreads();
+    }
 }
 
 // Bitmask path, last step on the class-partitioned route: the registered segments are dealt round-robin to the
@@ -2814,6 +2838,7 @@ struct vx_nms_ws {
     vx_bm_ws bm;                                              // bitmask path (capacities beyond the single-launch kernel only)
     int bm_on;
     int *plist, *pm;                                          // score-prefix lists (top_k; same capacities)
+    int *big_list; int big_cap;                               // vx_part_args::big_list
     unsigned *pthr;
     size_t bytes;
 };
@@ -2865,8 +2890,10 @@ static vx_nms_ws vx_nms_carve(void *ws, int B, int npad_cap) {
         w.plist = (int *)(p + off); off += vx_align256n((size_t)B * VX_PREFIX_CAP * sizeof(int));
         w.pm = (int *)(p + off); off += vx_align256n((size_t)B * sizeof(int));
         w.pthr = (unsigned *)(p + off); off += vx_align256n((size_t)B * sizeof(unsigned));
+        w.big_cap = B * (npad_cap / VX_PART_SMALL + 1);       // segments of more than VX_PART_SMALL keys
+        w.big_list = (int *)(p + off); off += vx_align256n((size_t)w.big_cap * sizeof(int));
     } else {
-        w.plist = nullptr; w.pm = nullptr; w.pthr = nullptr;
+        w.plist = nullptr; w.pm = nullptr; w.pthr = nullptr; w.big_list = nullptr; w.big_cap = 0;
     }
     w.bytes = off;
     return w;
@@ -3027,6 +3054,8 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         a.ordered = run_merge ? 1 : 0;
         a.defer = small_only; a.keep_counts = d_keep_counts;
         a.bm = w.bm; a.bm_on = w.bm_on;
+        // (the counter block is zeroed once per call, before vx_k_nms_image)
+        a.big_count = w.bm_on ? w.bm.counters + 3 : nullptr; a.big_list = w.big_list; a.big_cap = w.big_cap;
         pa = a;
         if (hipMemsetAsync(w.part_hist, 0, (size_t)2 * B * VX_PART_MAX_CLASSES * sizeof(int), st) != hipSuccess)
             return VX_ERR_LAUNCH;
@@ -3041,7 +3070,12 @@ static int vx_nms_impl(const float *d_boxes, const float *d_scores, const int64_
         if (small_lds < VX_BM_PREP_SCRATCH(VX_PART_SMALL)) small_lds = VX_BM_PREP_SCRATCH(VX_PART_SMALL);
         if (small_lds < vx_async_ring_bytes(8)) small_lds = vx_async_ring_bytes(8);
         hipLaunchKernelGGL((vx_k_part_sweep<VX_PART_SMALL, 512>), dim3(n_classes, B), dim3(512), small_lds, st, a);
-        hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(n_classes, B), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
+        if (a.big_count) {
+            int gb = w.big_cap < 512 ? w.big_cap : 512;
+            hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(gb), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
+        } else {
+            hipLaunchKernelGGL((vx_k_part_sweep<VX_SORT_CHMAX, 1024>), dim3(n_classes, B), dim3(1024), VX_SORT_CHMAX * sizeof(u64), st, a);
+        }
         vx_prof_end(VX_PROF_SWEEP, st);
         d_counts = w.sel2;                             // the general path below: images with a segment beyond the LDS sort
     }
@@ -3179,7 +3213,7 @@ extern "C" int vx_batched_nms_noalloc(const float *d_boxes, const float *d_score
 // Tuple packing (the `tuple(results)` of base_postprocess.py:131-138 without B Python slices):
 // rows [0, counts[b]) of every image are copied back to back; offsets[b] = sum(counts[0..b)).
 #define VX_PACK_ROWS 256
-#define VX_PACK_MAXG 16              // workgroups per image
+#define VX_PACK_MAXG 16              // workgroups per image (more for small batches)
 __global__ __launch_bounds__(256) void vx_k_pack_rows(const float *__restrict__ src, const int *__restrict__ counts,
                                                       int B, int cap, int D, float *__restrict__ dst,
                                                       int *__restrict__ total, const int *__restrict__ meta_src,
@@ -3231,7 +3265,8 @@ extern "C" int vx_pack_rows(const float *d_src, const int32_t *d_counts, int B, 
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_PACK, st);
     int gx = (capacity + VX_PACK_ROWS - 1) / VX_PACK_ROWS;
-    if (gx > VX_PACK_MAXG) gx = VX_PACK_MAXG;
+    const int maxg = 2048 / B > VX_PACK_MAXG ? 2048 / B : VX_PACK_MAXG;     // about 2048 workgroups in all
+    if (gx > maxg) gx = maxg;
     hipLaunchKernelGGL(vx_k_pack_rows, dim3(gx, B), dim3(256), 0, st, d_src,
                        d_counts, B, capacity, D, d_dst, d_total, d_meta_src, meta_dst, n_meta);
     vx_prof_end(VX_PROF_PACK, st);

@@ -31,7 +31,7 @@
 #define VX_BM_MIN 256                 // segments with more boxes than this take the bitmask path (<= 256: vx_sweep_wave)
 #define VX_BM_MAXN VX_SORT_CHMAX      // ... up to this many (ranks are 16-bit halves of an edge word; LDS tables of 256 tiles)
 #define VX_BM_ECAP 8                  // edge capacity per box of a segment
-#define VX_BM_COUNTER_BYTES 256       // counter block: [0] segments, [1] work items, [2] buckets of the run merge, [8..13] debug
+#define VX_BM_COUNTER_BYTES 256       // counter block: [0] segments, [1] work items, [2] buckets of the run merge, [3] large segments of the class partition, [8..13] debug
 #define VX_BM_STAGE 512               // edges staged per wave before a flush
 #define VX_BM_MAXEXP VX_SWEEP_MAXBIG  // exported segments per image on the single-launch route
 #define VX_BM_TRIP 4
