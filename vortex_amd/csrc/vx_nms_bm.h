@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr
     // Static deal of the work items, one wave each per round.  (A/B on MI355X: a device-side work queue -- eight
     // atomic heads, a look before each atomic -- balanced the tail but took 0.56 ms instead of 0.33 ms on the FPN-SSD
     // batch (27 000 short items) and 0.23 instead of 0.21 ms on RetinaFace: the returning atomics cost more than
-    // the imbalance.)
+    // the imbalance.  Dealing every item to Q waves (wave q visits the owned tiles A with A % Q == q) to shorten the
+    // heaviest items: RetinaFace 0.120 / 0.136 / 0.162 / 0.185 ms for Q = 1 / 2 / 3 / 4 -- the kernel is bound by its
+    // instruction throughput, not by its tail.)
     for (int it = blockIdx.x * 4 + wv; it < nitems; it += gridDim.x * 4) {
         // wave-uniform values are made so explicitly (readfirstlane): loads land in vector registers and everything
         // derived from them would be treated as divergent
