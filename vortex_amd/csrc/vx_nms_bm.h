@@ -482,6 +482,11 @@ struct vx_bm_scan_smem {
 // its longest suppression chain is deep (a box is decided once all its suppressors are: a handful of ballots) instead
 // of one scalar step per suppressing box, and the serial path per tile shrinks to: dead mask -> resolve -> dead-mask
 // atomics of the kept boxes' edges.
+// A/B (round 3, MI355X): the same chain as a PULL -- cross edges sorted by target tile in two lists (from the tile in
+// front / from further back), the far list resolved a turn ahead against the kept masks in LDS, the near list against
+// last turn's kept mask in a scalar register, both ORed over the wave by DPP, no LDS atomics on the serial path --
+// was not faster: vx_k_bm_finish 0.088 -> 0.096 ms on RetinaFace, vx_k_bm_scan 0.048 -> 0.053 ms on FPN-SSD.  One wave
+// issues ~250 dependent instructions per tile either way.
 typedef __attribute__((address_space(3))) unsigned vx_lds_u32;
 typedef __attribute__((address_space(3))) u64 vx_lds_u64;
 template <bool LDS_E, bool COLS>
