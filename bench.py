@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="2 = the pre-process runs on its own HIP stream, ordered after the decode kernel of the same "
                          "step, so the latency-bound NMS/pack tail overlaps the HBM-bound normalize; 1 = one stream")
+    ap.add_argument("--batch-streams", type=int, default=1,
+                    help="N > 1: whole steps go to N HIP streams in turn (needs --depth 2), so the kernels of step i+1 "
+                         "run beside the tail of step i wherever that tail leaves CUs or HBM bandwidth idle")
     ap.add_argument("--threshold-first", action="store_true",
                     help="opt-in decode variant (nan_check='survivors'): objectness plane first, other planes only "
                          "for surviving rows; same detections, NaN check restricted -> not the reference-exact line")
@@ -255,11 +258,17 @@ def main():
 
     ag_s = [0.0]            # host time inside allgather_detections (includes the wait for the step's kernels)
 
+    ring = V.StreamRing(args.batch_streams, dev) if args.batch_streams > 1 else None
+
     def run_steps(n):
         """n full steps; every step's per-image tuple is materialised before this returns."""
         out, prev = None, None
         for _ in range(n):
-            cur = step()
+            if ring is not None and args.depth > 1 and not args.allgather:
+                with ring.next():
+                    cur = step()
+            else:
+                cur = step()
             if args.depth > 1 and not args.allgather:
                 if prev is not None:
                     out = (prev[0], prev[1].result())
@@ -424,7 +433,7 @@ def main():
                        "parallelism": "dp%d (batch-sharded, no data-path collective%s)"
                                       % (n_gpus, "; all-gather of results" if args.allgather else ""),
                        "batches_in_flight": 1 if args.allgather else args.depth,
-                       "hip_streams": 2 if two_streams else 1},
+                       "hip_streams": 2 if two_streams else max(1, args.batch_streams)},
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "single process",
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
             "rank_devices": rank_devices,

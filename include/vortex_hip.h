@@ -322,6 +322,12 @@ int vx_profile_get(int slot, const char **name, int *launches, float *total_ms, 
  * set, the NMS sweeps add the number of IoU tests they execute on live lanes to it (one atomic add per wave and
  * class segment); NULL switches the counting off (the default).  Process-global, like the hooks above. */
 int vx_profile_set_iou_counter(uint64_t *d_counter);
+/* No counterpart in the reference.  Do kernels on stream_a and stream_b of this process run side by side?  HIP spreads a
+ * process's streams over a few hardware queues (GPU_MAX_HW_QUEUES), and two streams that share a queue run strictly one
+ * after the other.  The probe runs a one-wave ~0.1 ms dependent chain alone on stream_a, then one on each stream, and sets
+ * *overlap = 1 when the pair takes < 1.5x the single time (times in ms to ms_alone / ms_both, either may be NULL).
+ * Synchronises both streams; a set-up call, not a data-path one (vortex_amd.streams.StreamRing picks its pair with it). */
+int vx_streams_overlap(void *stream_a, void *stream_b, int *overlap, float *ms_alone, float *ms_both);
 /* Diagnostics of the single-launch NMS kernel: while profiling is enabled, workgroup b writes 8 shader-clock
  * stamps (keys, sort, gather, wave sweeps, block sweeps, second sort, output) as the first 8 words of u64[B][136] at
  * this byte offset of the workspace handed to vx_batched_nms (0 if the arguments are out of range); words 8.. hold,

@@ -49,7 +49,7 @@ def timed_repeats(loop, steps, min_repeats=5, min_total_s=0.3, max_repeats=40):
     return times
 
 
-def _timed(fn, steps, warmup, fn_async=None):
+def _timed(fn, steps, warmup, fn_async=None, ring=None, kernels=True):
     """fn() = one synchronous step.  With fn_async (returns an object whose .result() materialises the step's
     detections) the timed loop keeps two batches in flight exactly as bench.py's headline loop does (--depth 2).
     Returns (last result, median seconds per step, kernel times, spread record)."""
@@ -63,17 +63,24 @@ def _timed(fn, steps, warmup, fn_async=None):
             last[0] = out
             return out
         prev = None
-        for _ in range(n):
-            cur = fn_async()
+        for i in range(n):
+            if ring is not None:
+                with ring.next():
+                    cur = fn_async()
+            else:
+                cur = fn_async()
             if prev is not None:
                 prev.result()
             prev = cur
         last[0] = prev.result()
         return last[0]
+    torch.cuda.synchronize()
     loop(max(warmup, 1))
     times = timed_repeats(loop, steps)
     spread = _spread(times, steps)
     dt = spread["median_ms_per_step"] * 1e-3
+    if not kernels:
+        return last[0], dt, None, spread
     L.profile_enable(steps * 40)                      # separate pass: every kernel family bracketed by HIP events
     for _ in range(steps):
         fn()
@@ -81,6 +88,25 @@ def _timed(fn, steps, warmup, fn_async=None):
     kern = L.profile_read()
     L.profile_disable()
     return last[0], dt, {k: round(v["avg_ms"] * v["launches"] / steps, 5) for k, v in kern.items()}, spread
+
+
+_RING = {}
+
+
+def _two_streams(fn, fn_async, steps, warmup, out, B, dt1):
+    """The same two-batches-in-flight loop with the batches on two HIP streams in turn (vortex_amd.streams.StreamRing):
+    the pre-process and decode of batch i+1 run beside the one-workgroup-per-image NMS tail of batch i.  Same results."""
+    if _RING.get("off"):
+        return None
+    from vortex_amd.streams import StreamRing
+    if "ring" not in _RING:                       # one pair of streams per process, shared by every configuration
+        _RING["ring"] = StreamRing(2, _dev())
+    out2, dt2, _, spread2 = _timed(fn, steps, warmup, fn_async, ring=_RING["ring"], kernels=False)
+    assert len(out) == len(out2) and all(torch.equal(a, b) for a, b in zip(out, out2)), "two-stream results differ"
+    return {"images_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4), "spread": spread2,
+            "speedup_vs_one_stream": round(dt1 / dt2, 3),
+            "note": "batches alternate between two HIP streams (vortex_amd.streams.StreamRing); results checked equal to "
+                    "the one-stream loop's; kernels_ms / roofline / nms below are from the one-stream pass"}
 
 
 def _iou_tests(fn):
@@ -195,6 +221,7 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # single-class model whose images exceed 16384 candidates would lose that bet every time and switches it off
     pp.optimistic_nms = NL - 1 >= 4 or cand // B <= ops.NMS_SINGLE_LAUNCH_MAX
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
+    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
     # rows + priors once + the four output tensors (boxes 16, scores 4, labels 8, result rows 4 * (6 + 2L) bytes per
     # candidate; the staged records of rounds 1-2 are gone)
     algo = B * P * NCOL * 4 + P * 16 + cand * (52 + 8 * Lm)
@@ -202,7 +229,7 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # its last 16-byte chunk)
     in_regs = NCOL % 4 == 0 and 8 <= NCOL <= 16 and 4 + 2 * Lm >= NCOL - 4
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
            "roofline": _roof("vx_k_prior_decode_reg" if in_regs else "vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
@@ -249,8 +276,9 @@ def stress_cfg(steps=10, warmup=3, cpu_budget=8.0, top_k=300, tag="nms_stress_10
     def fn():
         return fn_async().result()
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
+    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
            "boxes_per_image": K, "candidates_per_image": int(counts.sum()) // B, "classes": C, "top_k": top_k,
            "thresholds": {"score": sthr, "iou": ithr},
            "detections_per_image": sum(int(r.shape[0]) for r in out) // B}
@@ -358,10 +386,11 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0, variants=True):
         pre()
         return post.forward_async(heads, st, it)
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
+    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
     cand = int(ops.yolo_fused_decode(heads, S, sthr).counts.sum())
     tag = "yolo416_b256_" + kind
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.2}}
     if kind == "resize720p":
@@ -443,7 +472,8 @@ if __name__ == "__main__":
     alias = {"ssd": "fpn_ssd_640_b64", "retinaface": "retinaface_640_b128", "stress": "nms_stress_100k_b32_top300",
              "dense": "yolo416_b256_dense", "resize": "yolo416_b256_resize720p", "stress_all": "nms_stress_100k_b32_all",
              "b1": "yolo416_b1_latency", "resize_only": "yolo416_b256_resize720p_only"}
-    args = [a for a in sys.argv[1:] if a != "--no-cpu"]
+    _RING["off"] = "--one-stream" in sys.argv      # profiling runs: keep overlapped launches out of the kernel statistics
+    args = [a for a in sys.argv[1:] if a not in ("--no-cpu", "--one-stream")]
     which = [alias.get(a, a) for a in args] or None
     for k, v in run_configs(which, cpu="--no-cpu" not in sys.argv).items():
         print(json.dumps({"config": k, **v}), flush=True)

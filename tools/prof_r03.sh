@@ -9,12 +9,12 @@ for TAG in "$@"; do
     default)      CMD="bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-variants --configs none" ;;
     dense)        CMD="bench.py --dense --steps 30 --warmup 5 --no-cpu-baseline --no-variants --configs none" ;;
     unfused)      CMD="bench.py --unfused --steps 30 --warmup 5 --no-cpu-baseline --no-variants --configs none" ;;
-    retinaface)   CMD="tools/bench_configs.py retinaface --no-cpu" ;;
-    fpn_ssd)      CMD="tools/bench_configs.py ssd --no-cpu" ;;
-    stress)       CMD="tools/bench_configs.py stress --no-cpu" ;;
-    stress_all)   CMD="tools/bench_configs.py stress_all --no-cpu" ;;
-    resize720p)   CMD="tools/bench_configs.py resize_only --no-cpu" ;;
-    dense_cfg)    CMD="tools/bench_configs.py dense --no-cpu" ;;
+    retinaface)   CMD="tools/bench_configs.py retinaface --no-cpu --one-stream" ;;
+    fpn_ssd)      CMD="tools/bench_configs.py ssd --no-cpu --one-stream" ;;
+    stress)       CMD="tools/bench_configs.py stress --no-cpu --one-stream" ;;
+    stress_all)   CMD="tools/bench_configs.py stress_all --no-cpu --one-stream" ;;
+    resize720p)   CMD="tools/bench_configs.py resize_only --no-cpu --one-stream" ;;
+    dense_cfg)    CMD="tools/bench_configs.py dense --no-cpu --one-stream" ;;
     b1)           CMD="tools/bench_configs.py b1 --no-cpu" ;;
     *) echo "unknown tag $TAG"; exit 2 ;;
     esac

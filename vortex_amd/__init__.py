@@ -26,5 +26,6 @@ from .prior import PriorBoxDecoder, PriorBoxPostProcess  # noqa: F401
 from .detr import DETRPostProcess  # noqa: F401
 from .predictor import BasePredictor, create_predictor, get_prediction_results  # noqa: F401
 from .step import YoloV3PipelineStep  # noqa: F401
+from .streams import StreamRing  # noqa: F401
 
 __version__ = "0.1.0"

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "vx_profile_disable": (c_int, []),
     "vx_profile_slots": (c_int, []),
     "vx_profile_set_iou_counter": (c_int, [c_void_p]),
+    "vx_streams_overlap": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_float),
+                                   ctypes.POINTER(c_float)]),
     "vx_batched_nms_stamps_offset": (c_size_t, [c_int, c_int]),
     "vx_batched_nms_bm_counters_offset": (c_size_t, [c_int, c_int]),
     "vx_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_int),

@@ -104,3 +104,55 @@ extern "C" int vx_profile_set_iou_counter(uint64_t *d_counter) {
     g_iou_counter = (unsigned long long *)d_counter;
     return VX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Do two streams of this process run kernels side by side?  HIP spreads a process's streams over a few hardware
+// queues; two streams that share one run their kernels strictly one after the other, whatever the kernels leave idle.
+// The probe runs a one-wave dependent-FMA chain alone on stream_a, then one on each stream, and compares the times.
+static __device__ float vx_spin_sink;
+
+__global__ __launch_bounds__(64) void vx_k_spin(int iters) {
+    float x = (float)threadIdx.x;
+    for (int i = 0; i < iters; ++i) x = __builtin_fmaf(x, 0.99999994f, 1.0f);
+    if (x == -1.0f) vx_spin_sink = x;                  // never true: keeps the chain alive
+}
+
+extern "C" int vx_streams_overlap(void *stream_a, void *stream_b, int *overlap, float *ms_alone, float *ms_both) {
+    if (!overlap) return VX_ERR_INVALID_ARG;
+    hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    const int iters = 40000;                              // ~0.1 ms
+    float alone = 0.f, both = 0.f;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(vx_k_spin, dim3(1), dim3(64), 0, sa, iters);   // both queues exist, clocks are up
+        hipLaunchKernelGGL(vx_k_spin, dim3(1), dim3(64), 0, sb, iters);
+        ok = hipStreamSynchronize(sa) == hipSuccess && hipStreamSynchronize(sb) == hipSuccess;
+    }
+    // best of three rounds each: a round disturbed by anything else on the GPU only ever reads longer
+    for (int r = 0; r < 3 && ok; ++r) {
+        float t = 0.f, tb = 0.f;
+        ok = hipEventRecord(e0, sa) == hipSuccess;
+        hipLaunchKernelGGL(vx_k_spin, dim3(1), dim3(64), 0, sa, iters);
+        ok = ok && hipEventRecord(e1, sa) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+        if (ok && (r == 0 || t < alone)) alone = t;
+        if (!ok) break;
+        ok = hipEventRecord(e0, sa) == hipSuccess;
+        hipLaunchKernelGGL(vx_k_spin, dim3(1), dim3(64), 0, sa, iters);
+        hipLaunchKernelGGL(vx_k_spin, dim3(1), dim3(64), 0, sb, iters);
+        ok = ok && hipEventRecord(e1, sa) == hipSuccess && hipEventRecord(e2, sb) == hipSuccess &&
+             hipEventSynchronize(e1) == hipSuccess && hipEventSynchronize(e2) == hipSuccess &&
+             hipEventElapsedTime(&t, e0, e1) == hipSuccess && hipEventElapsedTime(&tb, e0, e2) == hipSuccess;
+        t = t > tb ? t : tb;
+        if (ok && (r == 0 || t < both)) both = t;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (!ok) return VX_ERR_LAUNCH;
+    *overlap = both < 1.5f * alone ? 1 : 0;
+    if (ms_alone) *ms_alone = alone;
+    if (ms_both) *ms_both = both;
+    return VX_OK;
+}
