@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="2 = the pre-process runs on its own HIP stream, ordered after the decode kernel of the same "
                          "step, so the latency-bound NMS/pack tail overlaps the HBM-bound normalize; 1 = one stream")
+    ap.add_argument("--head-launches", action="store_true",
+                    help="--unfused only: the three YoloV3Layer decodes as three launches (vx_yolo_head_decode) instead "
+                         "of one (vx_yolo_head_decode3)")
     ap.add_argument("--batch-streams", type=int, default=1,
                     help="N > 1: whole steps go to N HIP streams in turn (needs --depth 2), so the kernels of step i+1 "
                          "run beside the tail of step i wherever that tail leaves CUs or HBM bandwidth idle")
@@ -228,6 +231,7 @@ def main():
             G = h.shape[-1]
             layers.append((V.YoloV3Layer(S, (G, G), list(mask), ops.COCO_ANCHORS, C).to(dev).eval(), off))
             off += 3 * G * G
+        head3 = V.YoloV3HeadDecode(S, C).to(dev).eval() if not args.head_launches else None
         post = V.YoloV3PostProcess(img_size=S)
         decoded = torch.empty((B, R, 5 + C), device=dev)
     else:
@@ -244,8 +248,11 @@ def main():
         x = norm(imgs[turn[0]])                             # K1 (consumed by the backbone, out of scope)
         inp = heads
         if args.unfused:
-            for (layer, off), h in zip(layers, heads):
-                layer(h, out=decoded, row_offset=off)
+            if head3 is not None:
+                head3(*heads, out=decoded)                  # YoloV3Layer x3 + concat, one launch
+            else:
+                for (layer, off), h in zip(layers, heads):
+                    layer(h, out=decoded, row_offset=off)
             inp = decoded
         if args.allgather:
             packed, meta = post.forward_device(inp, sthr, ithr)

@@ -106,6 +106,14 @@ int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G, int C,
                         const float anchor_wh[6], float stride,
                         int64_t out_batch_stride /* floats between images in d_out */,
                         int64_t row_offset, void *stream);
+/* The three scales in ONE launch: YoloV3Layer x3 (heads/detection/yolov3.py:263-304) + the concat of YoloV3.forward
+ * (networks/models/detection/yolov3.py:72-76).  d_in0/1/2 = raw heads coarse -> fine, f32[B, 3*(5+C), G, G] with
+ * G = img_size/32, /16, /8; d_out f32[B, R, 5+C], R = 3*sum(G*G), rows in the reference's order (coarse scale first).
+ * anchors_px = the 9 (w,h) anchors in pixels; scale k uses masks (6,7,8), (3,4,5), (0,1,2) (:319-343) and
+ * anchors / stride in fp32 (:244).  Same arithmetic, same bits as three vx_yolo_head_decode calls; the small scales
+ * fill the tail of the large one instead of paying a launch ramp each.  d_out 16-byte aligned, 5+C <= 255. */
+int vx_yolo_head_decode3(const float *d_in0, const float *d_in1, const float *d_in2, float *d_out, int B,
+                         int img_size, int C, const float anchors_px[18], void *stream);
 
 /* ---------------------------------------------------------------- K3 YOLOv3 decoder
  * Replaces YoloV3Decoder.forward (networks/modules/postprocess/yolov3.py:29-68, yolo2xywh :9-17)

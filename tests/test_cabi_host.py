@@ -48,6 +48,10 @@ def test_argument_checks_return_codes_without_gpu():
     assert lib.vx_yolo_head_decode(p, p, 1, 13, 300, L.f6([1] * 6), 32.0, 507 * 305, 0, None) == -2
     assert lib.vx_yolo_head_decode(p, p + 4, 1, 13, 80, L.f6([1] * 6), 32.0, 507 * 85, 0, None) == -5
     assert lib.vx_yolo_head_decode(p, p, 1, 13, 80, L.f6([1] * 6), 32.0, 100, 0, None) == -1
+    assert lib.vx_yolo_head_decode3(p, p, None, p, 1, 416, 80, L.f18([1] * 18), None) == -1
+    assert lib.vx_yolo_head_decode3(p, p, p, p, 1, 16, 80, L.f18([1] * 18), None) == -1
+    assert lib.vx_yolo_head_decode3(p, p, p, p + 4, 1, 416, 80, L.f18([1] * 18), None) == -5
+    assert lib.vx_yolo_head_decode3(p, p, p, p, 1, 416, 300, L.f18([1] * 18), None) == -2
     assert lib.vx_yolo_decode(p, 1, 100, 80, 416.0, 0.5, 1, p, p, p, p, p, p, p, 16, None) == -3
     assert lib.vx_batched_nms(p, p, p, p, None, 1, 2_000_000, 6, 0, 0.5, 0, p, p, p, 2_000_000, p, p, 1 << 40, None) == -2
     assert lib.vx_batched_nms(p, p, p, p, None, 1, 10, 6, 0, -0.5, 0, p, p, p, 10, p, p, 1 << 30, None) == -2

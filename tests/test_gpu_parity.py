@@ -122,6 +122,30 @@ def test_yolo_head_concat_416_and_extremes():
     close(out, ref)
 
 
+@pytest.mark.parametrize("S,C,B", [(416, 80, 3), (320, 20, 2), (96, 1, 5), (608, 3, 1)])
+def test_yolo_head_decode3_one_launch_equals_three_layers_and_oracle(S, C, B):
+    """vx_yolo_head_decode3 (YoloV3Layer x3 + concat in one launch): the bits of the three single-scale launches, and
+    the oracle's YoloV3Layer restatement to 1e-5 (grids with cells % 4 != 0 take the scalar loads inside the launch)."""
+    heads = O.synth_yolo_heads(B, S, C, seed=11 + S)
+    heads[0][0, 4, 0, 0] = 60.0
+    heads[2][B - 1, 2, 1, 1] = -40.0
+    hd = [h.to(DEV) for h in heads]
+    out3 = torch.full((B, ops.yolo_rows(S), 5 + C), float("nan"), device=DEV)
+    off = 0
+    for h, mask in zip(hd, O.ANCHOR_MASKS):
+        G = h.shape[-1]
+        V.YoloV3Layer(S, (G, G), list(mask), O.COCO_ANCHORS, C).to(DEV).eval()(h, out=out3, row_offset=off)
+        off += 3 * G * G
+    mod = V.YoloV3HeadDecode(S, C).to(DEV).eval()
+    out1 = mod(*hd)
+    assert out1.shape == out3.shape and torch.equal(out1, out3)
+    close(out1, O.yolo_head_eval(heads, S))
+    buf = torch.full_like(out3, float("nan"))
+    assert mod(*hd, out=buf) is buf and torch.equal(buf, out3)
+    with pytest.raises(RuntimeError):
+        V.YoloV3HeadDecode(S, C + 1)(*hd)
+
+
 # ------------------------------------------------------------------------------------------- K3
 @pytest.mark.parametrize("tname,thr", [("t50", 0.5), ("t06", 0.06), ("t00", 0.0), ("t90", 0.9)])
 def test_yolo_decoder_golden_bit_exact(golden, tname, thr):

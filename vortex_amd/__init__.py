@@ -18,7 +18,7 @@ reference's own nn.Module API for that path:
 """
 from . import _lib, ops, runtime  # noqa: F401
 from .preprocess import Normalize, FlipNormalize, get_preprocess  # noqa: F401
-from .heads import YoloV3Layer, yolo_feature_maps  # noqa: F401
+from .heads import YoloV3Layer, YoloV3HeadDecode, yolo_feature_maps  # noqa: F401
 from .postprocess import (YoloV3Decoder, BatchedNMS, NMS, NoNMS, BasicNMSPostProcess,  # noqa: F401
                           BatchedNMSPostProcess, YoloV3PostProcess, YoloV3FusedPostProcess,
                           NoOpPostProcess, SoftmaxPostProcess, batched_nms, get_postprocess)

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "vx_resize_u8hwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vx_yolo_head_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _F6, c_float,
                                     c_int64, c_int64, c_void_p]),
+    "vx_yolo_head_decode3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, _F18, c_void_p]),
     "vx_yolo_decode_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vx_yolo_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

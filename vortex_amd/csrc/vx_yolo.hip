@@ -10,6 +10,16 @@
 #include "vx_common.h"
 #include "vx_profile.h"
 
+// Workgroups go to the 8 XCDs in turn (blockIdx % 8), each with an L2 of its own.  A tile's channel runs are 256 B at
+// a 64-byte alignment (a plane of 52 x 52 cells is 10816 B), so every other run shares a 128-byte line with the next
+// tile of the plane: with neighbouring tiles on different XCDs both fetch it (PMC: 1.31x the algorithmic reads).  The
+// remap gives every XCD one contiguous eighth of the tiles, so neighbours run on one L2 a moment apart.
+__device__ __forceinline__ int vx_xcd_tile(int blk, int n) {
+    const int chunk = (n + 7) >> 3, t = (blk & 7) * chunk + (blk >> 3);
+    return t < min(n, ((blk & 7) + 1) * chunk) ? t : -1;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // K2: one workgroup = 64 consecutive cells of one (image, anchor) plane, all 5+C channels.
 // Load: channel-major, 64 consecutive cells per channel (coalesced).  The decoded values go to LDS
@@ -27,10 +37,8 @@ struct vx_head_params {
 // per channel plane, 43 KiB of LDS) 0.181 ms; two 64-cell tiles per workgroup with the loads of the second in flight
 // behind the copy-out of the first 0.143 ms.
 template <bool VEC>
-__global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__restrict__ in,
-                                                             float *__restrict__ out, vx_head_params p) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    int blk = blockIdx.x;
+__device__ __forceinline__ void vx_head_tile(const float *__restrict__ in, float *__restrict__ out, const vx_head_params &p,
+                                             int blk, float *__restrict__ tile) {
     int t = blk % p.tiles_per_plane;
     int pa = blk / p.tiles_per_plane;          // b*3 + a
     int a = pa % 3, b = pa / 3;
@@ -95,6 +103,92 @@ __global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__rest
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void vx_k_yolo_head_decode(const float *__restrict__ in,
+                                                             float *__restrict__ out, vx_head_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int blk = vx_xcd_tile(blockIdx.x, p.B * 3 * p.tiles_per_plane);
+    if (blk >= 0) vx_head_tile<VEC>(in, out, p, blk, tile);
+}
+
+// The three scales of a YOLOv3 head in ONE launch (YoloV3Layer x3 + the concat of models/detection/yolov3.py:72-76):
+// the grid is the tiles of the largest scale, then the next, then the smallest, so the two small scales -- 4.2 and
+// 3.7 TB/s as launches of their own (ramp-up and tail of a 0.08 / 0.02 ms kernel) -- fill the tail of the large one.
+struct vx_head3_params {
+    vx_head_params s[3];
+    const float *in[3];
+    int blk_end[3];
+    int vec[3];
+};
+
+__global__ __launch_bounds__(256) void vx_k_yolo_head_decode3(float *__restrict__ out, vx_head3_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int blk = vx_xcd_tile(blockIdx.x, p.blk_end[2]);
+    if (blk < 0) return;
+    const int k = blk < p.blk_end[0] ? 0 : (blk < p.blk_end[1] ? 1 : 2);
+    const int local = blk - (k == 0 ? 0 : p.blk_end[k - 1]);
+    if (p.vec[k]) vx_head_tile<true>(p.in[k], out, p.s[k], local, tile);
+    else vx_head_tile<false>(p.in[k], out, p.s[k], local, tile);
+}
+
+static int vx_head_setup(vx_head_params &p, int B, int G, int C, const float *anchor_wh, float stride,
+                         int64_t out_batch_stride, int64_t row_offset, long long *nblk) {
+    if (B <= 0 || G <= 0 || C < 0 || out_batch_stride <= 0 || row_offset < 0) return VX_ERR_INVALID_ARG;
+    int NP = 5 + C;
+    if (NP > 255) return VX_ERR_UNSUPPORTED;
+    long long cells = (long long)G * G;
+    if ((row_offset + 3 * cells) * NP > out_batch_stride) return VX_ERR_INVALID_ARG;
+    p.B = B; p.G = G; p.cells = (int)cells; p.NP = NP;
+    p.tiles_per_plane = (int)((cells + 63) / 64);
+    p.stride = stride;
+    for (int a = 0; a < 3; ++a) { p.aw[a] = anchor_wh[2 * a]; p.ah[a] = anchor_wh[2 * a + 1]; }
+    p.out_batch_stride = out_batch_stride; p.row_offset = row_offset;
+    *nblk = (long long)B * 3 * p.tiles_per_plane;
+    if (*nblk > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+    return VX_OK;
+}
+
+static int vx_yolo_rows(int S);
+
+extern "C" int vx_yolo_head_decode3(const float *d_in0, const float *d_in1, const float *d_in2, float *d_out, int B,
+                                    int img_size, int C, const float anchors_px[18], void *stream) {
+    if (!d_in0 || !d_in1 || !d_in2 || !d_out || !anchors_px) return VX_ERR_INVALID_ARG;
+    if (img_size < 32) return VX_ERR_INVALID_ARG;
+    const int mask[3][3] = {{6, 7, 8}, {3, 4, 5}, {0, 1, 2}};      // heads/detection/yolov3.py:319-343
+    if ((uintptr_t)d_out & 15) return VX_ERR_ALIGNMENT;
+    const float *in[3] = {d_in0, d_in1, d_in2};                     // coarse -> fine, as the reference concatenates them
+    const int R = vx_yolo_rows(img_size);
+    vx_head3_params p;
+    long long end = 0, row = 0;
+    long long rows0[3];
+    for (int k = 0; k < 3; ++k) { rows0[k] = row; int G = img_size / (32 >> k); row += 3LL * G * G; }
+    for (int j = 0; j < 3; ++j) {                                   // grid order: finest (largest) scale first
+        const int k = 2 - j;
+        if ((uintptr_t)in[k] & 3) return VX_ERR_ALIGNMENT;
+        const int G = img_size / (32 >> k);
+        const float stride = (float)((double)img_size / (double)G);    // heads/detection/yolov3.py:236
+        float awh[6];
+        for (int a = 0; a < 3; ++a) {                                  // anchors / stride in fp32 (:244)
+            awh[2 * a] = anchors_px[2 * mask[k][a]] / stride;
+            awh[2 * a + 1] = anchors_px[2 * mask[k][a] + 1] / stride;
+        }
+        long long nblk = 0;
+        int rc = vx_head_setup(p.s[j], B, G, C, awh, stride, (int64_t)R * (5 + C), rows0[k], &nblk);
+        if (rc != VX_OK) return rc;
+        end += nblk;
+        if (end > 0x7fffffffLL) return VX_ERR_UNSUPPORTED;
+        p.in[j] = in[k];
+        p.blk_end[j] = (int)end;
+        p.vec[j] = ((long long)G * G % 4 == 0) && (((uintptr_t)in[k] & 15) == 0);
+    }
+    size_t lds = (size_t)(64 * (5 + C) + 4) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    vx_prof_begin(VX_PROF_HEAD_DECODE, st);
+    hipLaunchKernelGGL(vx_k_yolo_head_decode3, dim3((unsigned)(8 * ((end + 7) / 8))), dim3(256), lds, st, d_out, p);
+    vx_prof_end(VX_PROF_HEAD_DECODE, st);
+    return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
+}
+
 extern "C" int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G, int C,
                                    const float anchor_wh[6], float stride, int64_t out_batch_stride,
                                    int64_t row_offset, void *stream) {
@@ -117,8 +211,9 @@ extern "C" int vx_yolo_head_decode(const float *d_in, float *d_out, int B, int G
     bool vec = (cells % 4 == 0) && (((uintptr_t)d_in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     vx_prof_begin(VX_PROF_HEAD_DECODE, st);
-    if (vec) hipLaunchKernelGGL(vx_k_yolo_head_decode<true>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
-    else     hipLaunchKernelGGL(vx_k_yolo_head_decode<false>, dim3((unsigned)nblk), dim3(256), lds, st, d_in, d_out, p);
+    const dim3 grid((unsigned)(8 * ((nblk + 7) / 8)));              // vx_xcd_tile
+    if (vec) hipLaunchKernelGGL(vx_k_yolo_head_decode<true>, grid, dim3(256), lds, st, d_in, d_out, p);
+    else     hipLaunchKernelGGL(vx_k_yolo_head_decode<false>, grid, dim3(256), lds, st, d_in, d_out, p);
     vx_prof_end(VX_PROF_HEAD_DECODE, st);
     return hipGetLastError() == hipSuccess ? VX_OK : VX_ERR_LAUNCH;
 }
@@ -595,8 +690,13 @@ template <int UN, bool NT, bool SPARSE>
 __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
                                                        int *__restrict__ tile_counts, int *__restrict__ status) {
     // 32-bit index math (the host refuses B * tiles_per_img >= 2^31): no 64-bit division per wave
-    const unsigned wtile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wtile >= (unsigned)p.B * (unsigned)p.tiles_per_img) return;
+    // XCD-contiguous workgroup order (vx_xcd_tile): workgroups that share a 128-byte line at their plane-run boundary
+    // run on one L2
+    const unsigned waves = (unsigned)p.B * (unsigned)p.tiles_per_img;
+    const int wg = vx_xcd_tile((int)blockIdx.x, (int)((waves + 3u) >> 2));
+    if (wg < 0) return;
+    const unsigned wtile = (unsigned)wg * 4u + (threadIdx.x >> 6);
+    if (wtile >= waves) return;
     int b = (int)(wtile / (unsigned)p.tiles_per_img);
     int t = (int)(wtile - (unsigned)b * (unsigned)p.tiles_per_img);
     int si, a, cell0;
@@ -862,13 +962,13 @@ static int vx_fused_decode_impl(const float *d_head0, const float *d_head1, cons
     // same box (tools/micro/read_bw.hip): linear 16-B nt read 7.1 TB/s, this kernel's plane-strided address pattern
     // without arithmetic 6.5 (2 planes in flight) .. 6.9 (12), linear read + sigmoid/max arithmetic 6.8.
     if (sparse)
-        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
+        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
     else if (waves <= VX_SPLIT_MAX_TILES && C >= 2 * VX_SPLIT_WAVES)
         hipLaunchKernelGGL(vx_k_yolo_fused_split, dim3((unsigned)waves), dim3(64 * VX_SPLIT_WAVES), 0, st, p, stage,
                            tile_counts, d_status);
     else
-        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, p, stage,
+        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
     vx_prof_end(VX_PROF_FUSED, st);
     if (info) {

@@ -58,3 +58,22 @@ class YoloV3Layer(nn.Module):
         if self.n_anchors != 3 or nx != ny or ch != 3 * self.n_predict:
             raise RuntimeError("vx_yolo_head_decode expects 3 anchors and a square grid, got %s" % (tuple(prediction.shape),))
         return ops.yolo_head_decode(prediction, self._anchor_wh_host, self._stride_host, out=out, row_offset=row_offset)
+
+
+class YoloV3HeadDecode(nn.Module):
+    """The eval tail of the reference's YoloV3 model in one kernel launch: its three YoloV3Layer decodes and
+    `torch.cat((h1, h2, h3), 1)` (networks/models/detection/yolov3.py:72-76; layers and masks as built at
+    heads/detection/yolov3.py:319-343).  forward(h1, h2, h3) takes the raw conv outputs coarse -> fine and returns
+    f32[B, R, 5+C], the tensor YoloV3PostProcess consumes -- the same bits as three YoloV3Layer calls."""
+
+    def __init__(self, img_size: int, n_classes: int, anchors: List[Tuple[int, int]] = None):
+        super().__init__()
+        self.img_size, self.n_classes = int(img_size), int(n_classes)
+        self.anchors = ops.COCO_ANCHORS if anchors is None else [tuple(a) for a in anchors]
+        assert len(self.anchors) == 9
+
+    def forward(self, h1: torch.Tensor, h2: torch.Tensor, h3: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        if h1.size(1) != 3 * (self.n_classes + 5):
+            raise RuntimeError("vx_yolo_head_decode3 expects 3 anchors x (5 + %d) channels, got %s"
+                               % (self.n_classes, tuple(h1.shape),))
+        return ops.yolo_head_decode3((h1, h2, h3), self.img_size, self.anchors, out=out)

@@ -125,6 +125,34 @@ def yolo_head_decode(x: torch.Tensor, anchor_wh: Sequence[float], stride: float,
     return out
 
 
+@_on_device
+def yolo_head_decode3(heads: Sequence[torch.Tensor], img_size: int, anchors=None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Three raw heads (coarse -> fine, f32[B,3(5+C),G,G], G = S/32, S/16, S/8) -> f32[B,R,5+C] in ONE launch
+    (vx_yolo_head_decode3): YoloV3Layer x3 + the concat of YoloV3.forward, same bits as three yolo_head_decode calls."""
+    assert len(heads) == 3
+    hs = []
+    for h, d in zip(heads, (32, 16, 8)):
+        L.require_cuda(h, "head")
+        assert h.dtype == torch.float32 and h.dim() == 4 and h.size(2) == img_size // d == h.size(3)
+        hs.append(h.contiguous())
+    B, ch = hs[0].shape[:2]
+    assert ch % 3 == 0 and all(h.size(0) == B and h.size(1) == ch for h in hs)
+    NP = ch // 3
+    R = yolo_rows(img_size)
+    if out is None:
+        out = torch.empty((B, R, NP), dtype=torch.float32, device=hs[0].device)
+    assert out.is_contiguous() and tuple(out.shape) == (B, R, NP) and out.dtype == torch.float32
+    if B == 0:
+        return out
+    anchors = COCO_ANCHORS if anchors is None else anchors
+    rc = L.lib().vx_yolo_head_decode3(hs[0].data_ptr(), hs[1].data_ptr(), hs[2].data_ptr(), out.data_ptr(), B,
+                                      int(img_size), NP - 5, L.f18([float(v) for a in anchors for v in a]),
+                                      L.stream_ptr(hs[0].device))
+    L.check(rc, "vx_yolo_head_decode3")
+    return out
+
+
 class Candidates:
     """Dense per-image candidate lists produced by a decoder (device buffers, capacity R)."""
     __slots__ = ("boxes", "scores", "cls", "det", "meta", "B", "R", "D")
