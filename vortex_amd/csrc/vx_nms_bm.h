@@ -358,7 +358,10 @@ __global__ __launch_bounds__(256) void vx_k_bm_pairs(const vx_bm_ws w, float thr
     // batch (27 000 short items) and 0.23 instead of 0.21 ms on RetinaFace: the returning atomics cost more than
     // the imbalance.  Dealing every item to Q waves (wave q visits the owned tiles A with A % Q == q) to shorten the
     // heaviest items: RetinaFace 0.120 / 0.136 / 0.162 / 0.185 ms for Q = 1 / 2 / 3 / 4 -- the kernel is bound by its
-    // instruction throughput, not by its tail.)
+    // instruction throughput, not by its tail.  An XCD-contiguous deal (every XCD one run of whole images, so a
+    // segment's records are fetched by one L2 instead of all eight: 102 MB read for 14 MB of records) left RetinaFace at
+    // 0.120 ms and cost FPN-SSD 0.153 -> 0.187 and the 100k stress 0.386 -> 0.463 ms: the XCDs' shares are uneven, and
+    // the reads were never the bound.)
     for (int it = blockIdx.x * 4 + wv; it < nitems; it += gridDim.x * 4) {
         // wave-uniform values are made so explicitly (readfirstlane): loads land in vector registers and everything
         // derived from them would be treated as divergent

@@ -42,6 +42,13 @@ typedef float vx_v4u __attribute__((ext_vector_type(4), aligned(4)));
 #define VX_PRIOR_REG_RB 128           // register kernel: rows per wave and batch
 #define VX_PRIOR_REG_NB 2             // batches per wave (A/B on the RetinaFace batch: 256x1 0.1125 ms, 128x2 0.108 ms)
 #endif
+// register kernel: ordinary (not non-temporal) row loads, so the rows of the survivors, which phase 2 reads again, are
+// still in the XCD's L2 (PMC: 483 MB read for 414 MB of input with non-temporal loads; A/B RetinaFace 0.1072 -> 0.1044 ms)
+#ifdef VX_PRIOR_NT_LD
+#define VX_PRIOR_LD(p) __builtin_nontemporal_load(p)
+#else
+#define VX_PRIOR_LD(p) (*(p))
+#endif
 #define VX_PRIOR_REG_GROUP (4 * VX_PRIOR_REG_RB * VX_PRIOR_REG_NB)
 
 template <int LIST>
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode_reg(const float *__rest
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
         const int c = k * 64 + lane;
-        q[k] = __builtin_nontemporal_load(reinterpret_cast<const vx_v4u *>(c < nchunk ? g + 4 * c : img));
+        q[k] = VX_PRIOR_LD(reinterpret_cast<const vx_v4u *>(c < nchunk ? g + 4 * c : img));
     }
     bool nan = false;
     int wcount = 0;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void vx_k_prior_decode_reg(const float *__rest
             const vx_v4u v = q[k];
             if (nb + 1 < NB) {                                      // refill behind the use: the next batch's chunk
                 const int cn = c + NQ * 64;
-                q[k] = __builtin_nontemporal_load(reinterpret_cast<const vx_v4u *>(cn < nchunk ? g + 4 * cn : img));
+                q[k] = VX_PRIOR_LD(reinterpret_cast<const vx_v4u *>(cn < nchunk ? g + 4 * cn : img));
             }
             const bool inside = c < nchunk;
             nan |= inside & (__builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w));
