@@ -7,7 +7,9 @@
  * hipStream_t passed as void*; kernels are launched on it with the CURRENT HIP
  * device, which must be the device the pointers live on.  No entry point
  * allocates, frees or synchronises: the caller owns outputs and workspace (sizes
- * from the *_workspace_bytes queries) and reads counts / status words back itself.
+ * from the *_workspace_bytes queries) and reads counts / status words back itself
+ * (one exception, a set-up probe outside the data path: vx_streams_overlap waits
+ * for the two streams it is given).
  * Process-global state the library keeps (all per device, set up on first use,
  * thread-safe): the "large dynamic LDS" attribute of four kernels, one hipEvent
  * for vx_yolo_fused_postprocess_overlapped, the address of the static scratch of

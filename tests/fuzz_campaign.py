@@ -64,6 +64,9 @@ def yolo_case(seed):
         ok = ok and torch.equal(a.det[b, :k], t.det[b, :k]) and torch.equal(a.scores[b, :k], t.scores[b, :k])
         keep = O.batched_nms(a.boxes[b, :k].cpu(), a.scores[b, :k].cpu(), a.cls[b, :k].cpu(), it)
         ok = ok and torch.equal(res[b].cpu(), a.det[b, :k].cpu()[keep])
+    # the one-launch head decode (three scales + concat) against the oracle's YoloV3Layer restatement (1e-5)
+    dec = V.YoloV3HeadDecode(S, C)(*dheads).cpu()
+    ok = ok and dec.shape == pred.shape and bool(((dec - pred).abs() <= 1e-5 * pred.abs() + 1e-6).all())
     return ok, dict(kind="yolo", seed=seed, S=S, C=C, B=B, sthr=sthr, ithr=ithr)
 
 
