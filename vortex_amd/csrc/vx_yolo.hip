@@ -686,6 +686,12 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
     return true;
 }
 
+#ifndef VX_FUSED_AB_UN
+#define VX_FUSED_AB_UN 2
+#endif
+#ifndef VX_FUSED_AB_NT
+#define VX_FUSED_AB_NT true
+#endif
 template <int UN, bool NT, bool SPARSE>
 __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec *__restrict__ stage,
                                                        int *__restrict__ tile_counts, int *__restrict__ status) {
@@ -959,16 +965,17 @@ static int vx_fused_decode_impl(const float *d_head0, const float *d_head1, cons
     // <2, true>: 2 channel planes per register batch in ping-pong (7 waves/SIMD), non-temporal loads.
     // A/B on MI355X, B=256 (tools/ab_fused.py): UN 8/4/3/2/1 with nt = 5.0/5.9/5.9/6.19/5.96 TB/s, UN 4/2 plain = 5.5/5.67;
     // one batch of 4/5/8/10/16/20 planes without ping-pong = 5.88/5.98/5.97/6.02/6.10/5.70.  Ceilings measured on the
+    // With the XCD-contiguous workgroup order (round 3): UN 2/3/4 with nt = 6.40/5.92/5.92 TB/s, UN 2/4 plain = 5.80/5.41.
     // same box (tools/micro/read_bw.hip): linear 16-B nt read 7.1 TB/s, this kernel's plane-strided address pattern
     // without arithmetic 6.5 (2 planes in flight) .. 6.9 (12), linear read + sigmoid/max arithmetic 6.8.
     if (sparse)
-        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, true>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
+        hipLaunchKernelGGL((vx_k_yolo_fused<VX_FUSED_AB_UN, VX_FUSED_AB_NT, true>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
     else if (waves <= VX_SPLIT_MAX_TILES && C >= 2 * VX_SPLIT_WAVES)
         hipLaunchKernelGGL(vx_k_yolo_fused_split, dim3((unsigned)waves), dim3(64 * VX_SPLIT_WAVES), 0, st, p, stage,
                            tile_counts, d_status);
     else
-        hipLaunchKernelGGL((vx_k_yolo_fused<2, true, false>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
+        hipLaunchKernelGGL((vx_k_yolo_fused<VX_FUSED_AB_UN, VX_FUSED_AB_NT, false>), dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), 0, st, p, stage,
                            tile_counts, d_status);
     vx_prof_end(VX_PROF_FUSED, st);
     if (info) {
