@@ -489,6 +489,27 @@ def test_fused_nan_check_modes():
         same(g, r)
 
 
+def test_fused_nan_reaches_the_status_word_from_the_streaming_kernel():
+    """A batch large enough for the one-wave-per-tile decode kernel (more tiles than the split kernel takes): a NaN in
+    any plane of any image raises, through the tile-count bit the staged decode reports it with; no NaN, no error, and
+    the detections equal the decoded-tensor path's."""
+    S, C, B = 96, 80, 400
+    heads = [h.to(DEV) for h in O.synth_yolo_heads(B, S, C, seed=47)]
+    st, it = torch.tensor([0.5]), torch.tensor([0.45])
+    post = V.YoloV3FusedPostProcess(S)
+    ref = V.YoloV3PostProcess(S)(V.YoloV3HeadDecode(S, C)(*heads), st, it)
+    got = post(heads, st, it)
+    assert len(got) == B
+    for b in (0, 1, B // 2, B - 1):
+        same(got[b], ref[b])
+    for hi, b, ch, y, x in ((2, B - 1, 5 + 63, 3, 7), (0, 0, 2, 1, 1), (1, 123, 85 + 4, 5, 0)):
+        hs = [h.clone() for h in heads]
+        hs[hi][b, ch, y, x] = float("nan")
+        with pytest.raises(ValueError):
+            post(hs, st, it)
+    assert len(post(heads, st, it)) == B                      # the next clean call is clean again
+
+
 # ------------------------------------------------------------------------------------------- DETR (§8f-1)
 def _detr_check(x, thr, expected):
     """conf within 1e-5 rel (softmax/exp), boxes and labels exact, same rows kept in the same order.  A query

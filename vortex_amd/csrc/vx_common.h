@@ -91,7 +91,13 @@ struct vx_stage_info {
     const int *tile_counts;               // [B][tiles]
     int tiles, R;
     int tile_base[3], tiles_per_plane[3], tile_cells[3], row_base[3], cells[3];
+    // set by the CALLER of vx_internal_yolo_fused_stage: `zero_words` ints at `zero_ptr` that the decode kernel clears
+    // for the kernel behind it (the chain's status word, the packing hand-off words) -- one fill launch less per batch.
+    // The decode kernel itself then needs no zeroed word: a tile that saw a NaN says so in bit 30 of its count.
+    int *zero_ptr;
+    int zero_words;
 };
+#define VX_TILE_NAN 0x40000000
 __host__ __device__ __forceinline__ int vx_stage_tile_row0(const vx_stage_info &f, int t) {
     const int si = (t >= f.tile_base[2]) ? 2 : (t >= f.tile_base[1] ? 1 : 0);
     const int tt = t - f.tile_base[si];

@@ -2470,6 +2470,10 @@ __device__ __forceinline__ int vx_image_finish(const vx_image_args &a, int b) {
     const int t = threadIdx.x;
     int c = 0, row0 = 0;
     if (t < f.tiles) { c = f.tile_counts[(long long)b * f.tiles + t]; row0 = vx_stage_tile_row0(f, t); }
+    // a tile of the decode that saw a NaN says so in bit 30 of its count (the decode kernel touches no status word)
+    const bool tile_nan = (c & VX_TILE_NAN) != 0;
+    c &= ~VX_TILE_NAN;
+    if (__ballot(tile_nan) != 0ull && lane == 0) vx_status_or(a.status, VX_STATUS_NAN);
     int incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }

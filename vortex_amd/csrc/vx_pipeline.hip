@@ -102,16 +102,17 @@ static int vx_pipe_impl(const float *d_head0, const float *d_head1, const float 
     const bool from_stage = vx_next_pow2(R) <= 16384;
     // ... and packs the kept rows too when its B workgroups are all resident at once
     const bool pack_in_kernel = from_stage && B <= vx_pipe_cus();
-    if (pack_in_kernel) {
-        if (hipMemsetAsync(w.sync, 0, w.sync_bytes, st) != hipSuccess) return VX_ERR_LAUNCH;
-        status = w.sync + 2;
-    // (the status word of the chain then lives next to that kernel's hand-off words: ONE fill of whole 256-byte lines)
-    // Otherwise only the status word is cleared (it is accumulated by atomicOr; counts and keep_counts are written for
-    // every image; a memset of all 2B+1 words is split by the runtime into two fill kernels, ~4 us each).
-    } else if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
-        return VX_ERR_LAUNCH;
-    }
+    // The words the chain needs zeroed -- its status word (accumulated by atomicOr) and, when the NMS kernel packs, that
+    // kernel's hand-off words, the status word among them -- are cleared by the decode kernel itself when it stages its
+    // records for the NMS kernel (vx_stage_info.zero_ptr; the decode then reports a NaN through its tile counts, not
+    // through the status word): no fill launch in front of the chain (4 us of GPU time + a launch gap per batch).
+    // Without staging only the status word is cleared, by a fill (counts and keep_counts are written for every image;
+    // a memset of all 2B+1 words is split by the runtime into two fill kernels).
+    if (pack_in_kernel) status = w.sync + 2;
+    if (!from_stage && hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return VX_ERR_LAUNCH;
     vx_stage_info info = {};
+    info.zero_ptr = pack_in_kernel ? w.sync : status;
+    info.zero_words = pack_in_kernel ? (int)(w.sync_bytes / sizeof(int)) : 1;
     int rc = from_stage
                  ? vx_internal_yolo_fused_stage(d_head0, d_head1, d_head2, B, S, C, anchors_px, score_threshold, use_threshold,
                                                 status, w.fused, w.fused_bytes, stream, &info)

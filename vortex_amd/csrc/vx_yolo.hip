@@ -361,7 +361,16 @@ struct vx_fused_params {
     float img_size, thr;
     int use_thr;
     int sparse_max;     // threshold-first: tiles with more survivors than this are streamed
+    // staged mode (vx_internal_yolo_fused_stage; consumed by vx_image_finish): a NaN is reported in bit 30 of the tile's
+    // count instead of an atomic on the status word, and the kernel clears zero_words ints at zero_ptr (vx_stage_info)
+    int nan_in_counts, zero_words;
+    int *zero_ptr;
 };
+
+__device__ __forceinline__ void vx_fused_zero(const vx_fused_params &p) {
+    if (p.zero_words > 0)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_words; i += gridDim.x * blockDim.x) p.zero_ptr[i] = 0;
+}
 
 __device__ __forceinline__ int vx_fused_tile_row0(const vx_fused_params &p, int t, int &si, int &a, int &cell0) {
     si = (t >= p.s[2].tile_base) ? 2 : (t >= p.s[1].tile_base ? 1 : 0);
@@ -471,7 +480,8 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
 #pragma unroll
             for (int j = 0; j < V; ++j) nan |= (tb[ch].v[j] != tb[ch].v[j]);
     }
-    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    const bool wnan = __ballot(nan) != 0;
+    if (wnan && !p.nan_in_counts && lane == 0) atomicOr(status, VX_STATUS_NAN);
     float obj[V];
     bool pass[V];
     u64 m[V];
@@ -498,7 +508,7 @@ __device__ __forceinline__ void vx_fused_tile(const vx_fused_params &p, const vx
             ++pos;
         }
     }
-    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total | ((wnan && p.nan_in_counts) ? VX_TILE_NAN : 0);
 }
 
 // Small batches (fewer tiles than the GPU has wave slots): one wave per tile leaves the kernel bound by a single
@@ -512,6 +522,8 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused_split(vx_fused_params p, 
     constexpr int V = 4;
     __shared__ float s_best[VX_SPLIT_WAVES][VX_WAVE * V];
     __shared__ int s_bi[VX_SPLIT_WAVES][VX_WAVE * V];
+    __shared__ int s_nan[VX_SPLIT_WAVES];
+    vx_fused_zero(p);
     const int b = blockIdx.x / p.tiles_per_img, t = blockIdx.x - b * p.tiles_per_img;
     const int lane = vx_lane(), w = threadIdx.x >> 6;
     int si, a, cell0;
@@ -564,7 +576,9 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused_split(vx_fused_params p, 
             }
         }
     }
-    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    const bool wnan = __ballot(nan) != 0;
+    if (wnan && !p.nan_in_counts && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    if (lane == 0) s_nan[w] = wnan ? 1 : 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) { s_best[w][lane * V + j] = best[j]; s_bi[w][lane * V + j] = bi[j]; }
     __syncthreads();
@@ -604,7 +618,8 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused_split(vx_fused_params p, 
             ++pos;
         }
     }
-    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + t] = total;
+    const bool tnan = p.nan_in_counts && (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) != 0;
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + t] = total | (tnan ? VX_TILE_NAN : 0);
 }
 
 // "Threshold first" tile: the objectness plane is read first (coalesced, 1/(5+C) of the bytes); a tile with
@@ -681,8 +696,9 @@ __device__ __forceinline__ bool vx_fused_tile_sparse(const vx_fused_params &p, c
         }
         if (pass[j]) ++mypos;
     }
-    if (__ballot(nan) != 0 && lane == 0) atomicOr(status, VX_STATUS_NAN);
-    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total;
+    const bool wnan = __ballot(nan) != 0;
+    if (wnan && !p.nan_in_counts && lane == 0) atomicOr(status, VX_STATUS_NAN);
+    if (lane == 0) tile_counts[(long long)b * p.tiles_per_img + tile] = total | ((wnan && p.nan_in_counts) ? VX_TILE_NAN : 0);
     return true;
 }
 
@@ -698,6 +714,7 @@ __global__ __launch_bounds__(256) void vx_k_yolo_fused(vx_fused_params p, vx_rec
     // 32-bit index math (the host refuses B * tiles_per_img >= 2^31): no 64-bit division per wave
     // XCD-contiguous workgroup order (vx_xcd_tile): workgroups that share a 128-byte line at their plane-run boundary
     // run on one L2
+    vx_fused_zero(p);
     const unsigned waves = (unsigned)p.B * (unsigned)p.tiles_per_img;
     const int wg = vx_xcd_tile((int)blockIdx.x, (int)((waves + 3u) >> 2));
     if (wg < 0) return;
@@ -949,6 +966,11 @@ static int vx_fused_decode_impl(const float *d_head0, const float *d_head1, cons
     if (rc != VX_OK) return rc;
     if (p.R > VX_MAX_CANDIDATES) return VX_ERR_UNSUPPORTED;
     p.img_size = (float)S; p.thr = score_threshold; p.use_thr = (use_threshold & 1) ? 1 : 0;
+    if (info) {                                        // staged mode: vx_image_finish reads the counts (and their NaN bit)
+        p.nan_in_counts = 1;
+        p.zero_ptr = info->zero_words > 0 ? info->zero_ptr : nullptr;
+        p.zero_words = p.zero_ptr ? info->zero_words : 0;
+    }
     const bool sparse = p.use_thr && (use_threshold & VX_DECODE_THRESHOLD_FIRST);
     // A/B on MI355X, B=256 (tools/ab_fused.py; streaming = 0.150-0.177 ms at every threshold): 8 -> 0.015 / 0.046 /
     // 0.118 / 0.158 / 0.167 / 0.176 ms at thr 0.9 / 0.7 / 0.5 / 0.3 / 0.2 / 0.06; 16 and 32 lose up to 2.3x at 0.2-0.3;
