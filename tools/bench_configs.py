@@ -128,6 +128,9 @@ def _nms_record(tests, nms_ms):
     rate = tests / (nms_ms * 1e-3)
     return {"iou_tests_per_step": tests, "nms_kernels_ms": round(nms_ms, 5), "iou_tests_per_s": round(rate, 1),
             "valu_peak_tests_per_s": IOU_PEAK_TESTS_PER_S, "frac_of_valu_peak": round(rate / IOU_PEAK_TESTS_PER_S, 4),
+            # a wave64 VALU instruction holds its SIMD for 4 cycles on gfx950 (tools/micro/sweep_loop.hip, SQ counters,
+            # DESIGN 5.0b): the rate a kernel can reach is 64 lanes/clk/CU, half the figure above
+            "frac_of_measured_valu_rate": round(rate / (IOU_PEAK_TESTS_PER_S / 2), 4),
             "note": "live-lane IoU tests counted on the device / summed NMS kernel time; peak = 256 CU x 128 lanes/clk x "
                     "2.4 GHz / 13 lane-ops per test"}
 
