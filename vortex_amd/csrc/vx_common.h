@@ -139,3 +139,13 @@ __host__ __device__ __forceinline__ int vx_next_pow2(int n) {
 
 // per-image row count as read from a caller-supplied device array: [0, cap] whatever the array holds
 __device__ __forceinline__ int vx_clamp_count(int c, int cap) { return c < 0 ? 0 : (c > cap ? cap : c); }
+
+// Workgroups go to the 8 XCDs in turn (blockIdx % 8), each with an L2 of its own.  A tile's channel runs are 256 B at
+// a 64-byte alignment (a plane of 52 x 52 cells is 10816 B), so every other run shares a 128-byte line with the next
+// tile of the plane: with neighbouring tiles on different XCDs both fetch it (PMC: 1.31x the algorithmic reads).  The
+// remap gives every XCD one contiguous eighth of the tiles, so neighbours run on one L2 a moment apart.
+// Launch 8 * ceil(n / 8) workgroups; a workgroup that gets -1 has no tile.
+__device__ __forceinline__ int vx_xcd_tile(int blk, int n) {
+    const int chunk = (n + 7) >> 3, t = (blk & 7) * chunk + (blk >> 3);
+    return t < min(n, ((blk & 7) + 1) * chunk) ? t : -1;
+}
