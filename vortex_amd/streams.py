@@ -49,8 +49,11 @@ class StreamRing:
                     have.append(cand)
                 else:
                     spare.append(cand)
-        have.extend(spare[:max(0, n - len(have))])     # more members asked for than queues: the rest share one
-        self.streams = have[:int(n)]
+        # `have` holds only streams that overlap pairwise (probed).  More members asked for than the probe found
+        # (fewer hardware queues, or a busy GPU that made the probe say no): the rest share a queue with somebody --
+        # the results are the same, those steps just run one after the other.
+        self.streams = (have + spare)[:int(n)]
+        self.overlapping = len(have) >= n
         self._k = 0
 
     def __len__(self):
