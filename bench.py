@@ -241,7 +241,8 @@ def main():
     if two_streams:
         # NMS + packing of a batch on a second stream behind the decode (vx_yolo_fused_postprocess_overlapped): the
         # current stream carries only K1 and the fused decode, back to back
-        post.tail_stream = torch.cuda.Stream(dev, priority=-1)
+        from vortex_amd.streams import overlapping_stream
+        post.tail_stream = overlapping_stream(torch.cuda.current_stream(dev))    # HIP maps streams to hardware queues unevenly
 
     def step():
         turn[0] = (turn[0] + 1) % len(imgs)

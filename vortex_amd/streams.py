@@ -21,6 +21,19 @@ def _overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     return bool(ov.value)
 
 
+def overlapping_stream(other: Optional["torch.cuda.Stream"] = None, tries: int = 8) -> "torch.cuda.Stream":
+    """A stream whose kernels run beside those of `other` (default: the current stream) -- probed with
+    vx_streams_overlap; the last candidate is returned if none of `tries` does."""
+    other = torch.cuda.current_stream() if other is None else other
+    cand = None
+    with torch.cuda.device(other.device):
+        for _ in range(max(1, tries)):
+            cand = torch.cuda.Stream(other.device)
+            if _overlap(other, cand):
+                break
+    return cand
+
+
 class StreamRing:
     """`with ring.next(): pending = postprocess.forward_async(...)` -- the step is enqueued on the ring's next stream,
     which first waits for what the caller's current stream still has in flight (the step's inputs), if anything.  The
