@@ -8,6 +8,7 @@
 Each record carries images/s, per-kernel times (the library's HIP-event hooks), the roofline of its dominant
 HBM-bound kernel, the NMS throughput in executed IoU tests/s against the VALU peak, and a time-boxed CPU baseline
 (the oracle, on a bounded sample).  Inputs are synthetic (SURVEY §8d distributions) and resident in HBM."""
+import collections
 import json
 import os
 import sys
@@ -49,7 +50,7 @@ def timed_repeats(loop, steps, min_repeats=5, min_total_s=0.3, max_repeats=40):
     return times
 
 
-def _timed(fn, steps, warmup, fn_async=None, ring=None, kernels=True):
+def _timed(fn, steps, warmup, fn_async=None, ring=None, kernels=True, depth=2):
     """fn() = one synchronous step.  With fn_async (returns an object whose .result() materialises the step's
     detections) the timed loop keeps two batches in flight exactly as bench.py's headline loop does (--depth 2).
     Returns (last result, median seconds per step, kernel times, spread record)."""
@@ -62,17 +63,18 @@ def _timed(fn, steps, warmup, fn_async=None, ring=None, kernels=True):
                 out = fn()
             last[0] = out
             return out
-        prev = None
+        pend = collections.deque()
         for i in range(n):
             if ring is not None:
                 with ring.next():
                     cur = fn_async()
             else:
                 cur = fn_async()
-            if prev is not None:
-                prev.result()
-            prev = cur
-        last[0] = prev.result()
+            pend.append(cur)
+            if len(pend) >= depth:
+                last[0] = pend.popleft().result()
+        while pend:
+            last[0] = pend.popleft().result()
         return last[0]
     torch.cuda.synchronize()
     loop(max(warmup, 1))
@@ -94,24 +96,29 @@ _RING = {}
 
 
 def _two_streams(fn, fn_async, steps, warmup, out, B, dt1):
-    """The same two-batches-in-flight loop with the batches on two HIP streams in turn (vortex_amd.streams.StreamRing):
-    the pre-process and decode of batch i+1 run beside the one-workgroup-per-image NMS tail of batch i.  Same results."""
+    """The same loop with the batches on three HIP streams in turn (vortex_amd.streams.StreamRing) and four in flight:
+    the pre-process and decode of the next batches run beside the one-workgroup-per-image NMS tail of this one.  Same
+    results.  A/B on MI355X (ms per step, RetinaFace / FPN-SSD / stress top-300 / stress all; one stream 0.546 / 0.623 /
+    0.134 / 0.940): 2 streams x 2 in flight 0.460 / 0.554 / 0.111 / 0.820; 2 x 3: 0.414 / 0.543 / 0.095 / 0.822;
+    3 x 3: 0.429 / 0.520 / 0.104 / 0.794; 3 x 4: 0.404 / 0.512 / 0.097 / 0.790; 3 x 5, 3 x 6, 4 x 5: no better."""
     if _RING.get("off"):
         return None
     from vortex_amd.streams import StreamRing
     try:
-        if "ring" not in _RING:                   # one pair of streams per process, shared by every configuration
-            _RING["ring"] = StreamRing(2, _dev())
-        out2, dt2, _, spread2 = _timed(fn, steps, warmup, fn_async, ring=_RING["ring"], kernels=False)
+        nring, depth = int(os.environ.get("VX_BENCH_RING", "3")), int(os.environ.get("VX_BENCH_RING_DEPTH", "4"))
+        if "ring" not in _RING:                   # one set of streams per process, shared by every configuration
+            _RING["ring"] = StreamRing(nring, _dev())
+        out2, dt2, _, spread2 = _timed(fn, steps, warmup, fn_async, ring=_RING["ring"], kernels=False, depth=depth)
         if not (len(out) == len(out2) and all(torch.equal(a, b) for a, b in zip(out, out2))):
             return {"error": "two-stream results differ from the one-stream loop's"}
     except Exception as e:                        # the variant must not take the configuration's record down
         torch.cuda.synchronize()
         return {"error": "%s: %s" % (type(e).__name__, e)}
     return {"images_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4), "spread": spread2,
+            "hip_streams": len(_RING["ring"]), "batches_in_flight": depth,
             "speedup_vs_one_stream": round(dt1 / dt2, 3), "streams_overlap": bool(_RING["ring"].overlapping),
-            "note": "batches alternate between two HIP streams (vortex_amd.streams.StreamRing); results checked equal to "
-                    "the one-stream loop's; kernels_ms / roofline / nms below are from the one-stream pass"}
+            "note": "batches go to the HIP streams of a vortex_amd.streams.StreamRing in turn; results checked equal to "
+                    "the one-stream loop's; kernels_ms / roofline / nms of the record are from the one-stream pass"}
 
 
 def _iou_tests(fn):
@@ -237,7 +244,7 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # its last 16-byte chunk)
     in_regs = NCOL % 4 == 0 and 8 <= NCOL <= 16 and 4 + 2 * Lm >= NCOL - 4
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
            "roofline": _roof("vx_k_prior_decode_reg" if in_regs else "vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
@@ -286,7 +293,7 @@ def stress_cfg(steps=10, warmup=3, cpu_budget=8.0, top_k=300, tag="nms_stress_10
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
     two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
            "boxes_per_image": K, "candidates_per_image": int(counts.sum()) // B, "classes": C, "top_k": top_k,
            "thresholds": {"score": sthr, "iou": ithr},
            "detections_per_image": sum(int(r.shape[0]) for r in out) // B}
@@ -398,7 +405,7 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0, variants=True):
     cand = int(ops.yolo_fused_decode(heads, S, sthr).counts.sum())
     tag = "yolo416_b256_" + kind
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "two_streams": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.2}}
     if kind == "resize720p":

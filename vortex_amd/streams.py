@@ -4,8 +4,8 @@ The NMS tail of a detection step (one workgroup per image, serial chains) leaves
 HBM-bound kernels in front of it (pre-process, decode) leave the VALUs idle: a serving loop that keeps two batches in
 flight gets both busy at once by giving each batch its own stream.  Every entry point of the library takes its
 stream, workspace and outputs from the caller ("thread-safety"), so two steps on two streams share
-nothing.  Measured on MI355X: RetinaFace 640 b128 0.55 -> 0.46 ms per step, FPN-SSD 640 b64 0.63 -> 0.55 ms; the
-YOLOv3 steps are HBM-bound end to end and gain nothing."""
+nothing.  Measured on MI355X, three streams with four batches in flight: RetinaFace 640 b128 0.546 -> 0.396 ms per
+step, FPN-SSD 640 b64 0.624 -> 0.511 ms; the YOLOv3 steps are HBM-bound end to end and gain nothing."""
 import contextlib
 import ctypes
 from typing import Optional
