@@ -6,7 +6,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_prior_postprocess_on_two_streams_equals_synchronous_calls():
+@pytest.mark.parametrize("nstreams", [2, 3])
+def test_prior_postprocess_on_several_streams_equals_synchronous_calls(nstreams):
     import vortex_amd as V
     from tools.bench_configs import make_priors
     dev = torch.device("cuda", 0)
@@ -23,7 +24,8 @@ def test_prior_postprocess_on_two_streams_equals_synchronous_calls():
         xs.append(x)
         imgs.append(torch.randint(0, 256, (B, 96, 96, 3), generator=g, dtype=torch.uint8, device=dev))
     want = [(norm(i), pp(x, st, it)) for i, x in zip(imgs, xs)]
-    ring = V.StreamRing(2, dev)
+    ring = V.StreamRing(nstreams, dev)
+    assert len(ring) == nstreams and len(set(s_.cuda_stream for s_ in ring.streams)) == nstreams
     pend = []
     for i, x in zip(imgs, xs):                              # all six in flight before the first result is read
         with ring.next():
