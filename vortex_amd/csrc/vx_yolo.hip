@@ -229,6 +229,8 @@ struct vx_rows_params {
 // Software-pipelined: a workgroup walks TPW consecutive tiles; the 16-B loads of tile j+1 are issued into
 // registers before tile j is reduced out of LDS, so HBM latency overlaps the class scan instead of preceding it.
 // A/B on MI355X, B=256, C=80 (tools/ab_unfused.py): TPW 1 / 2 / 4 / 8 = 4.77 / 5.55 / 4.30 / 3.94 TB/s.
+// Round 3: a persistent grid (1792 workgroups, workgroup w walks tiles w, w + grid, ... with the same prefetch) took 0.279 ms
+// against 0.166 -- the tiles in flight at any moment are then scattered over the whole tensor instead of one moving front.
 #define VX_K3_U 6
 template <int TPW>
 __global__ __launch_bounds__(256) void vx_k_yolo_decode_rows(const float *__restrict__ pred,
