@@ -95,7 +95,7 @@ def _timed(fn, steps, warmup, fn_async=None, ring=None, kernels=True, depth=2):
 _RING = {}
 
 
-def _two_streams(fn, fn_async, steps, warmup, out, B, dt1):
+def _multi_stream(fn, fn_async, steps, warmup, out, B, dt1):
     """The same loop with the batches on three HIP streams in turn (vortex_amd.streams.StreamRing) and four in flight:
     the pre-process and decode of the next batches run beside the one-workgroup-per-image NMS tail of this one.  Same
     results.  A/B on MI355X (ms per step, RetinaFace / FPN-SSD / stress top-300 / stress all; one stream 0.546 / 0.623 /
@@ -236,7 +236,7 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # single-class model whose images exceed 16384 candidates would lose that bet every time and switches it off
     pp.optimistic_nms = NL - 1 >= 4 or cand // B <= ops.NMS_SINGLE_LAUNCH_MAX
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
-    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
+    multi = _multi_stream(fn, fn_async, steps, warmup, out, B, dt)
     # rows + priors once + the four output tensors (boxes 16, scores 4, labels 8, result rows 4 * (6 + 2L) bytes per
     # candidate; the staged records of rounds 1-2 are gone)
     algo = B * P * NCOL * 4 + P * 16 + cand * (52 + 8 * Lm)
@@ -244,7 +244,7 @@ def prior_cfg(tag, B, Lm, NL, sthr, steps=10, warmup=3, cpu_budget=4.0):
     # its last 16-byte chunk)
     in_regs = NCOL % 4 == 0 and 8 <= NCOL <= 16 and 4 + 2 * Lm >= NCOL - 4
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": multi, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.4},
            "roofline": _roof("vx_k_prior_decode_reg" if in_regs else "vx_k_prior_decode", kern["vx_k_prior_decode"], algo, tag)}
@@ -291,9 +291,9 @@ def stress_cfg(steps=10, warmup=3, cpu_budget=8.0, top_k=300, tag="nms_stress_10
     def fn():
         return fn_async().result()
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
-    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
+    multi = _multi_stream(fn, fn_async, steps, warmup, out, B, dt)
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": multi, "kernels_ms": kern,
            "boxes_per_image": K, "candidates_per_image": int(counts.sum()) // B, "classes": C, "top_k": top_k,
            "thresholds": {"score": sthr, "iou": ithr},
            "detections_per_image": sum(int(r.shape[0]) for r in out) // B}
@@ -401,11 +401,11 @@ def yolo_cfg(kind, steps=20, warmup=5, cpu_budget=3.0, variants=True):
         pre()
         return post.forward_async(heads, st, it)
     out, dt, kern, spread = _timed(fn, steps, warmup, fn_async)
-    two = _two_streams(fn, fn_async, steps, warmup, out, B, dt)
+    multi = _multi_stream(fn, fn_async, steps, warmup, out, B, dt)
     cand = int(ops.yolo_fused_decode(heads, S, sthr).counts.sum())
     tag = "yolo416_b256_" + kind
     rec = {"images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "spread": spread, "batch": B,
-           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": two, "kernels_ms": kern,
+           "batches_in_flight": 2, "hip_streams": 1, "multi_stream": multi, "kernels_ms": kern,
            "candidates_per_image": cand // B, "detections_per_image": sum(int(r.shape[0]) for r in out) // B,
            "thresholds": {"score": sthr, "iou": 0.2}}
     if kind == "resize720p":
