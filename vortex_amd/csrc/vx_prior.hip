@@ -40,7 +40,8 @@ typedef float vx_v4u __attribute__((ext_vector_type(4), aligned(4)));
 #define VX_PRIOR_MAXGROUP (1 << VX_PRIOR_ROWBITS)
 #ifndef VX_PRIOR_REG_RB
 #define VX_PRIOR_REG_RB 128           // register kernel: rows per wave and batch
-#define VX_PRIOR_REG_NB 2             // batches per wave (A/B on the RetinaFace batch: 256x1 0.1125 ms, 128x2 0.108 ms)
+#define VX_PRIOR_REG_NB 2             // batches per wave (A/B on the RetinaFace batch: 256x1 0.1125 ms, 128x2 0.108 ms;
+                                      // with ordinary row loads 128x2 0.1038, 128x3 0.1095, 128x4 0.1075, 64x4 0.1058)
 #endif
 // register kernel: ordinary (not non-temporal) row loads, so the rows of the survivors, which phase 2 reads again, are
 // still in the XCD's L2 (PMC: 483 MB read for 414 MB of input with non-temporal loads; A/B RetinaFace 0.1072 -> 0.1044 ms)
